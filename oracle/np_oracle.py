@@ -1,0 +1,169 @@
+"""Independent numpy restatement of the post-processing path -- TEST INFRASTRUCTURE ONLY.
+
+Written separately from ``oracle/ypo.c`` (vectorised numpy float32 + plain Python loops
+for the greedy NMS) so the two can cross-check each other.  numpy's exp is not the
+bit-specified ``ypo_exp_spec``; decoded values therefore agree with the C oracle to a
+few ulp (tests use 1e-5 relative), while the NMS routines, which use only + - * / and
+comparisons, agree exactly when fed identical boxes.
+
+Mode R follows /root/reference/detect_net.py:152-183 (decode) and :90-146 (filter/NMS);
+Mode N follows the YOLOv3 tutorial semantics (not present in the reference).
+"""
+import numpy as np
+
+f32 = np.float32
+
+
+def sigmoid(x):
+    x = np.asarray(x, f32)
+    with np.errstate(over="ignore"):
+        return (f32(1.0) / (f32(1.0) + np.exp(-x))).astype(f32)
+
+
+# ------------------------------------------------------------------------------ Mode R
+
+def r_predict_transform(pred, H, W, A, C, anchors):
+    """detect_net.py:152-183."""
+    V = 5 + C
+    t = np.asarray(pred, f32).reshape(-1, H, W, A, V)                      # :153
+    k = np.arange(H * W)
+    idx = np.stack([k % H, k // H], 1).reshape(1, H, W, 1, 2).astype(f32)  # :155-162
+    dims = np.array([H, W], f32).reshape(1, 1, 1, 1, 2)                    # :163
+    center = (sigmoid(t[..., 0:2]) + idx) / dims                           # :166-168
+    obj = sigmoid(t[..., 4:5])                                             # :171
+    anc = np.asarray(anchors, f32).reshape(1, 1, 1, A, 2)                  # :173-174
+    with np.errstate(over="ignore"):
+        wh = (np.exp(t[..., 2:4]) * anc) / dims                            # :177
+    z = t[..., 5:5 + C]
+    e = np.exp(z - z.max(-1, keepdims=True))
+    s = np.zeros(e.shape[:-1] + (1,), f32)
+    for j in range(C):                                                     # sequential sum
+        s = s + e[..., j:j + 1]
+    cls = e / s                                                            # :180
+    return center.astype(f32), wh.astype(f32), obj.astype(f32), cls.astype(f32)
+
+
+def tf_iou(bi, bj):
+    bi, bj = np.asarray(bi, f32), np.asarray(bj, f32)
+    ymin_i, ymax_i = min(bi[0], bi[2]), max(bi[0], bi[2])
+    xmin_i, xmax_i = min(bi[1], bi[3]), max(bi[1], bi[3])
+    ymin_j, ymax_j = min(bj[0], bj[2]), max(bj[0], bj[2])
+    xmin_j, xmax_j = min(bj[1], bj[3]), max(bj[1], bj[3])
+    area_i = f32(ymax_i - ymin_i) * f32(xmax_i - xmin_i)
+    area_j = f32(ymax_j - ymin_j) * f32(xmax_j - xmin_j)
+    if area_i <= 0 or area_j <= 0:
+        return f32(0.0)
+    dh = max(f32(min(ymax_i, ymax_j) - max(ymin_i, ymin_j)), f32(0.0))
+    dw = max(f32(min(xmax_i, xmax_j) - max(xmin_i, xmin_j)), f32(0.0))
+    inter = f32(dh * dw)
+    return f32(inter / f32(f32(area_i + area_j) - inter))
+
+
+def tf_nms(boxes, scores, max_out, thr):
+    """Greedy NMS as tf.image.non_max_suppression (detect_net.py:136)."""
+    boxes = np.asarray(boxes, f32).reshape(-1, 4)
+    scores = np.asarray(scores, f32)
+    order = sorted(range(len(scores)), key=lambda i: (-float(scores[i]), i))
+    sel = []
+    thr = f32(thr)
+    for i in order:
+        if len(sel) >= max_out:
+            break
+        if all(not (tf_iou(boxes[i], boxes[s]) > thr) for s in sel):
+            sel.append(i)
+    return np.array(sel, np.int32)
+
+
+def r_filter_boxes(center, wh, obj, cls, conf_thr, nms_thr, max_boxes, im_h, im_w):
+    """detect_net.py:90-146."""
+    mins = center - wh / f32(2.0)                                          # :95
+    maxes = center + wh / f32(2.0)                                         # :96
+    boxes = np.concatenate([mins[..., 1:2], mins[..., 0:1],
+                            maxes[..., 1:2], maxes[..., 0:1]], -1)         # :97-102
+    sc = obj * cls                                                         # :107
+    bcls = sc.argmax(-1)                                                   # :108
+    bsc = sc.max(-1)                                                       # :109
+    mask = bsc >= f32(conf_thr)                                            # :111
+    dims = np.array([im_h, im_w, im_h, im_w], f32).reshape(1, 4)           # :115-116
+    out = ([], [], [], [])
+    surv = []
+    for b in range(center.shape[0]):                                       # :125
+        bb = boxes[b][mask[b]] * dims                                      # :126,133
+        ss = bsc[b][mask[b]]
+        cc = bcls[b][mask[b]].astype(np.int64)
+        surv.append(len(ss))
+        idx = tf_nms(bb, ss, max_boxes, nms_thr)                           # :136
+        out[0].append(bb[idx]); out[1].append(ss[idx])                     # :137-139
+        out[2].append(cc[idx]); out[3].append(idx)
+    return out[0], out[1], out[2], out[3], np.array(surv, np.int32)
+
+
+# ------------------------------------------------------------------------------ Mode N
+
+def n_predict_transform(head, inp_dim, anchors_px, num_classes):
+    head = np.asarray(head, f32)
+    B, ch, gh, gw = head.shape
+    A, C = len(anchors_px), num_classes
+    V = 5 + C
+    in_h, in_w = (inp_dim, inp_dim) if np.isscalar(inp_dim) else inp_dim
+    sx, sy = in_w // gw, in_h // gh
+    t = head.reshape(B, A, V, gh * gw).transpose(0, 3, 1, 2)               # (B, cell, A, V)
+    cell = np.arange(gh * gw)
+    col = (cell % gw).astype(f32).reshape(1, -1, 1)
+    row = (cell // gw).astype(f32).reshape(1, -1, 1)
+    anc = np.asarray(anchors_px, np.float64).reshape(A, 2)
+    aw = (anc[:, 0] / sx).astype(f32).reshape(1, 1, A)
+    ah = (anc[:, 1] / sy).astype(f32).reshape(1, 1, A)
+    out = np.empty((B, gh * gw, A, V), f32)
+    out[..., 0] = (sigmoid(t[..., 0]) + col) * f32(sx)
+    out[..., 1] = (sigmoid(t[..., 1]) + row) * f32(sy)
+    with np.errstate(over="ignore"):
+        out[..., 2] = (np.exp(t[..., 2]) * aw) * f32(sx)
+        out[..., 3] = (np.exp(t[..., 3]) * ah) * f32(sy)
+    out[..., 4] = sigmoid(t[..., 4])
+    out[..., 5:] = sigmoid(t[..., 5:])
+    return out.reshape(B, gh * gw * A, V)
+
+
+def n_iou(b1, b2):
+    b1, b2 = np.asarray(b1, f32), np.asarray(b2, f32)
+    one, zero = f32(1.0), f32(0.0)
+    dw = f32(f32(min(b1[2], b2[2]) - max(b1[0], b2[0])) + one)
+    dh = f32(f32(min(b1[3], b2[3]) - max(b1[1], b2[1])) + one)
+    inter = f32(max(dw, zero) * max(dh, zero))
+    a1 = f32(f32(f32(b1[2] - b1[0]) + one) * f32(f32(b1[3] - b1[1]) + one))
+    a2 = f32(f32(f32(b2[2] - b2[0]) + one) * f32(f32(b2[3] - b2[1]) + one))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return f32(inter / f32(f32(a1 + a2) - inter))
+
+
+def n_write_results(rows, confidence, num_classes, nms_conf=0.4):
+    rows = np.asarray(rows, f32)
+    B, N, V = rows.shape
+    C = num_classes
+    out = []
+    for b in range(B):
+        p = rows[b]
+        obj = p[:, 4]
+        keep = (obj > f32(confidence)) & (obj != 0)
+        p = p[keep]
+        if len(p) == 0:
+            continue
+        hw, hh = p[:, 2] / f32(2), p[:, 3] / f32(2)
+        box = np.stack([p[:, 0] - hw, p[:, 1] - hh, p[:, 0] + hw, p[:, 1] + hh], 1)
+        cscore = p[:, 5:5 + C].max(1)
+        cid = p[:, 5:5 + C].argmax(1)
+        for c in sorted(set(cid.tolist())):
+            sel = np.nonzero(cid == c)[0]
+            order = sorted(sel.tolist(), key=lambda i: (-float(p[i, 4]), i))
+            alive = list(order)
+            i = 0
+            while i < len(alive):
+                a = alive[i]
+                alive = alive[:i + 1] + [j for j in alive[i + 1:]
+                                         if n_iou(box[a], box[j]) < f32(nms_conf)]
+                i += 1
+            for a in alive:
+                out.append([b, box[a, 0], box[a, 1], box[a, 2], box[a, 3],
+                            p[a, 4], cscore[a], c])
+    return np.array(out, f32).reshape(-1, 8)
