@@ -1,0 +1,155 @@
+"""ctypes binding of libyolopost.so (the C ABI declared in include/yolopost.h).
+
+There is exactly one compute path: the HIP library.  If it is missing, or no ROCm device
+is usable, the calls raise -- nothing here falls back to PyTorch ops or to the CPU.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolopost.so")
+
+YP_MAX_HEADS = 4
+YP_MAX_ANCHORS = 8
+YP_MODE_YOLOV3 = 0
+YP_MODE_REFERENCE = 1
+
+# every symbol include/yolopost.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = (
+    "yp_version", "yp_strerror",
+    "yp_predict_transform_reference", "yp_predict_transform_yolov3",
+    "yp_detect_yolov3_workspace_bytes", "yp_detect_yolov3",
+    "yp_detect_reference_workspace_bytes", "yp_detect_reference",
+    "yp_rows_workspace_bytes", "yp_write_results", "yp_filter_boxes_reference",
+    "yp_bbox_iou",
+)
+
+
+class YpHead(ctypes.Structure):
+    _fields_ = [
+        ("data", ctypes.c_void_p),
+        ("grid_h", ctypes.c_int32),
+        ("grid_w", ctypes.c_int32),
+        ("num_anchors", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("stride_x", ctypes.c_float),
+        ("stride_y", ctypes.c_float),
+        ("anchors", ctypes.c_float * (2 * YP_MAX_ANCHORS)),
+    ]
+
+
+class YpParams(ctypes.Structure):
+    _fields_ = [
+        ("mode", ctypes.c_int32),
+        ("batch", ctypes.c_int32),
+        ("num_classes", ctypes.c_int32),
+        ("max_out", ctypes.c_int32),
+        ("conf_thr", ctypes.c_float),
+        ("nms_thr", ctypes.c_float),
+        ("im_h", ctypes.c_float),
+        ("im_w", ctypes.c_float),
+        ("batch_offset", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class YoloPostError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libyolopost.so; raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YoloPostError(
+            "libyolopost.so is missing at %s -- build it with "
+            "`make -C 2d_object_detection_amd/csrc` (or __graft_entry__.build()); there is no "
+            "fallback path" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.yp_version.restype = ctypes.c_int
+    L.yp_version.argtypes = []
+    L.yp_strerror.restype = ctypes.c_char_p
+    L.yp_strerror.argtypes = [i32]
+    L.yp_predict_transform_reference.restype = i32
+    L.yp_predict_transform_reference.argtypes = [vp, i32, i32, i32, i32, i32, fp, vp, vp, vp, vp, vp]
+    L.yp_predict_transform_yolov3.restype = i32
+    L.yp_predict_transform_yolov3.argtypes = [ctypes.POINTER(YpHead), i32, i32, i32, vp, vp]
+    L.yp_detect_yolov3_workspace_bytes.restype = sz
+    L.yp_detect_yolov3_workspace_bytes.argtypes = [ctypes.POINTER(YpHead), i32, i32, i32]
+    L.yp_detect_yolov3.restype = i32
+    L.yp_detect_yolov3.argtypes = [ctypes.POINTER(YpHead), i32, ctypes.POINTER(YpParams), vp, i64,
+                                   vp, vp, vp, sz, vp]
+    L.yp_detect_reference_workspace_bytes.restype = sz
+    L.yp_detect_reference_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.yp_detect_reference.restype = i32
+    L.yp_detect_reference.argtypes = [ctypes.POINTER(YpHead), ctypes.POINTER(YpParams), vp, vp, vp,
+                                      vp, vp, vp, vp, sz, vp]
+    L.yp_rows_workspace_bytes.restype = sz
+    L.yp_rows_workspace_bytes.argtypes = [i32, i32, i32]
+    L.yp_write_results.restype = i32
+    L.yp_write_results.argtypes = [vp, i32, ctypes.POINTER(YpParams), vp, i64, vp, vp, vp, sz, vp]
+    L.yp_filter_boxes_reference.restype = i32
+    L.yp_filter_boxes_reference.argtypes = [vp, vp, vp, vp, i32, ctypes.POINTER(YpParams), vp, vp,
+                                            vp, vp, vp, vp, vp, sz, vp]
+    L.yp_bbox_iou.restype = i32
+    L.yp_bbox_iou.argtypes = [vp, vp, i32, i32, vp, vp]
+    _lib = L
+    return L
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().yp_strerror(code).decode()
+        raise YoloPostError("%s failed: %s (code %d)" % (what, msg, code))
+
+
+def require_device(t, name):
+    """The kernels read raw device pointers: refuse anything that is not a ROCm tensor."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor, got %r" % (name, type(t)))
+    if not t.is_cuda:
+        raise YoloPostError(
+            "%s is on %s; this library only runs on a ROCm GPU (no CPU fallback exists)"
+            % (name, t.device))
+    return t
+
+
+def as_f32(t, name):
+    require_device(t, name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def workspace(nbytes, device):
+    """256-byte aligned device scratch (the caching allocator aligns to 512 B)."""
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    assert ws.data_ptr() % 256 == 0
+    return ws
+
+
+def make_head(t, grid_h, grid_w, anchors, stride_x=0.0, stride_y=0.0):
+    h = YpHead()
+    h.data = t.data_ptr() if t is not None else 0
+    h.grid_h, h.grid_w = int(grid_h), int(grid_w)
+    h.num_anchors = len(anchors)
+    h.stride_x, h.stride_y = float(stride_x), float(stride_y)
+    if len(anchors) > YP_MAX_ANCHORS:
+        raise YoloPostError("at most %d anchors per head are supported" % YP_MAX_ANCHORS)
+    for i, (w, hh) in enumerate(anchors):
+        h.anchors[2 * i] = float(w)
+        h.anchors[2 * i + 1] = float(hh)
+    return h

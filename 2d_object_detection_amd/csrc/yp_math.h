@@ -1,0 +1,134 @@
+// yp_math.h -- scalar binary32 arithmetic shared by every kernel of libyolopost.
+//
+// Everything here is a fixed sequence of IEEE-754 binary32 operations (floor, fma,
+// multiply, add, subtract, correctly rounded divide, comparisons).  Compiled with
+// -ffp-contract=off the GPU evaluates each function to the same bits as any conforming
+// CPU, which is what makes kept-box index sets reproducible.  The functions are
+// __host__ __device__ so a host-only build (tests/test_host_math.py compiles this header
+// with g++) can be compared against the CPU oracle without a GPU.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define YP_HD __host__ __device__ __forceinline__
+#else
+#define YP_HD static inline
+#endif
+
+YP_HD float yp_bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+YP_HD uint32_t yp_f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+// exp(x): k = floor(x*log2(e) + 0.5), r = x - k*ln2 (two-term ln2), degree-5 minimax tail
+// in Horner form with fma (Cephes expf coefficients), scaled by 2^k in two exact steps so
+// that both factors are normal numbers.  Max error 0.98 ulp on [-104, 88.7].
+YP_HD float yp_exp(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return __builtin_inff();
+    if (x < -103.97207641601562f) return 0.0f;
+    float kf = __builtin_floorf(__builtin_fmaf(x, 1.44269504088896341f, 0.5f));
+    float r = __builtin_fmaf(kf, -0.693359375f, x);
+    r = __builtin_fmaf(kf, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    p = __builtin_fmaf(p, r2, r);
+    p = p + 1.0f;
+    int k = (int)kf;
+    int k1 = k >> 1;
+    int k2 = k - k1;
+    float s1 = yp_bits2f((uint32_t)(k1 + 127) << 23);
+    float s2 = yp_bits2f((uint32_t)(k2 + 127) << 23);
+    return (p * s1) * s2;
+}
+
+YP_HD float yp_sigmoid(float x) { return 1.0f / (1.0f + yp_exp(-x)); }
+
+// A box as four floats.  YOLOv3 mode: (x1,y1,x2,y2).  Reference mode: (y1,x1,y2,x2).
+struct YpBox {
+    float a, b, c, d;
+};
+
+// A box prepared for repeated IoU tests: corners (normalised by min/max in reference mode)
+// and its area term.
+struct YpPrep {
+    float lo0, lo1, hi0, hi1, area;
+};
+
+// YOLOv3 tutorial bbox_iou, pixel-inclusive: area = (x2-x1+1)*(y2-y1+1).
+YP_HD YpPrep yp_prep_v3(const YpBox &q)
+{
+    YpPrep p;
+    p.lo0 = q.a; p.lo1 = q.b; p.hi0 = q.c; p.hi1 = q.d;
+    p.area = (q.c - q.a + 1.0f) * (q.d - q.b + 1.0f);
+    return p;
+}
+
+YP_HD float yp_iou_v3(const YpPrep &p, const YpPrep &q)
+{
+    const float i0 = p.lo0 > q.lo0 ? p.lo0 : q.lo0;
+    const float i1 = p.lo1 > q.lo1 ? p.lo1 : q.lo1;
+    const float j0 = p.hi0 < q.hi0 ? p.hi0 : q.hi0;
+    const float j1 = p.hi1 < q.hi1 ? p.hi1 : q.hi1;
+    float d0 = j0 - i0 + 1.0f;
+    float d1 = j1 - i1 + 1.0f;
+    if (!(d0 > 0.0f)) d0 = 0.0f;
+    if (!(d1 > 0.0f)) d1 = 0.0f;
+    const float inter = d0 * d1;
+    return inter / (p.area + q.area - inter);
+}
+
+// tf.image.non_max_suppression IoU (the call at detect_net.py:136): corners normalised by
+// min/max, no +1, a box of non-positive area has IoU 0 with everything.
+YP_HD YpPrep yp_prep_tf(const YpBox &q)
+{
+    YpPrep p;
+    p.lo0 = q.a < q.c ? q.a : q.c;
+    p.lo1 = q.b < q.d ? q.b : q.d;
+    p.hi0 = q.a > q.c ? q.a : q.c;
+    p.hi1 = q.b > q.d ? q.b : q.d;
+    p.area = (p.hi0 - p.lo0) * (p.hi1 - p.lo1);
+    return p;
+}
+
+YP_HD float yp_iou_tf(const YpPrep &p, const YpPrep &q)
+{
+    if (p.area <= 0.0f || q.area <= 0.0f) return 0.0f;
+    const float i0 = p.lo0 > q.lo0 ? p.lo0 : q.lo0;
+    const float i1 = p.lo1 > q.lo1 ? p.lo1 : q.lo1;
+    const float j0 = p.hi0 < q.hi0 ? p.hi0 : q.hi0;
+    const float j1 = p.hi1 < q.hi1 ? p.hi1 : q.hi1;
+    float d0 = j0 - i0;
+    float d1 = j1 - i1;
+    if (!(d0 > 0.0f)) d0 = 0.0f;
+    if (!(d1 > 0.0f)) d1 = 0.0f;
+    const float inter = d0 * d1;
+    return inter / (p.area + q.area - inter);
+}
+
+// Does the earlier (higher-score) box p suppress the later box q?
+//   YOLOv3 mode:    the later box survives only if IoU < thr   -> suppress = !(iou < thr)
+//   reference mode: the later box is dropped when IoU > thr    -> suppress = iou > thr
+template <int MODE>
+YP_HD YpPrep yp_prep(const YpBox &q)
+{
+    return MODE == 0 ? yp_prep_v3(q) : yp_prep_tf(q);
+}
+
+template <int MODE>
+YP_HD bool yp_suppresses(const YpPrep &p, const YpPrep &q, float thr)
+{
+    if (MODE == 0) return !(yp_iou_v3(p, q) < thr);
+    return yp_iou_tf(p, q) > thr;
+}
+
+// Order-preserving map float -> uint32 (unsigned compare == float compare, NaN excluded).
+YP_HD uint32_t yp_float_order_bits(float f)
+{
+    uint32_t u = yp_f2bits(f + 0.0f);  // +0.0f turns -0 into +0
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}

@@ -1,0 +1,80 @@
+"""Image-level data parallelism for the post-processing path.
+
+Images are independent (the reference itself loops over them, detect_net.py:125), so a
+batch is split into contiguous slices, one per rank (one process per GPU); decode, filter
+and NMS run with no communication.  The only exchange is a final variable-length
+all-gather of detection rows: first one count per rank, then one padded all-gather sized to
+the largest count.  Payloads are KB..MB, i.e. latency-bound on xGMI, hence two
+collectives in total rather than one per image.  With the ``nccl`` backend (RCCL on ROCm)
+the tensors stay on the GPU; the ``gloo`` backend is used by the CPU tests of this
+index arithmetic.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(batch, world_size, rank):
+    """Contiguous slice [lo, hi) of a batch owned by ``rank``; the first ``batch %
+    world_size`` ranks get one extra image."""
+    if world_size <= 0 or not 0 <= rank < world_size:
+        raise ValueError("bad rank/world_size")
+    q, r = divmod(int(batch), int(world_size))
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def all_gather_rows(rows, count=None, group=None):
+    """Variable-length all-gather along dim 0.
+
+    ``rows`` is this rank's (n_r, W) tensor (or a (cap, W) buffer of which the first
+    ``count`` rows are valid; ``count`` may be an int or a one-element tensor).  Returns
+    (gathered (sum n_r, W) ordered by rank, counts list).  Every rank gets the same
+    result."""
+    if not dist.is_initialized():
+        raise RuntimeError("torch.distributed is not initialised")
+    world = dist.get_world_size(group)
+    n = rows.shape[0] if count is None else int(count)
+    n = min(n, rows.shape[0])
+    dev = rows.device
+    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    width = rows.shape[1:]
+    m = max(counts)
+    if m == 0:
+        return rows.new_zeros((0,) + tuple(width)), counts
+    send = rows.new_zeros((m,) + tuple(width))
+    send[:n] = rows[:n]
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    return torch.cat([r[:c] for r, c in zip(recv, counts)], dim=0), counts
+
+
+class ShardedYoloV3Post:
+    """One rank's share of a global batch: a ``YoloV3Post`` over the rank's slice whose
+    image indices are offset to global numbering, plus the final all-gather.  The gathered
+    (D, 8) tensor is identical on every rank and identical to a single-GPU run over the
+    whole batch (order: image, class id, objectness descending)."""
+
+    def __init__(self, global_batch, inp_dim, num_classes=5, confidence=0.5, nms_conf=0.4,
+                 device=None, group=None, **kw):
+        from .util import YoloV3Post
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.lo, self.hi = shard_bounds(global_batch, self.world, self.rank)
+        if self.hi <= self.lo:
+            raise ValueError("global batch smaller than the number of ranks")
+        self.engine = YoloV3Post(self.hi - self.lo, inp_dim, num_classes, confidence, nms_conf,
+                                 device=device, batch_offset=self.lo, **kw)
+
+    def run_local(self, local_heads):
+        return self.engine.run(local_heads)
+
+    def detect(self, local_heads):
+        out, count = self.engine.run(local_heads)
+        if self.world == 1:
+            return out[:int(count.item())]
+        gathered, _ = all_gather_rows(out, int(count.item()), self.group)
+        return gathered

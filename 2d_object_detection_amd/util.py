@@ -1,0 +1,215 @@
+"""YOLOv3 three-stride post-processing: ``predict_transform``, ``write_results``,
+``bbox_iou`` with the signatures of the YOLOv3 tutorial the reference credits
+(README.md:1), plus ``YoloV3Post``, the fused raw-heads -> detections engine.
+
+These functions are not part of the reference repository (its own path is the single-grid
+``DetectNet`` in detect_net.py); they are the semantics the project brief names.  Tensors
+are ``torch.Tensor`` on a ROCm device; all arithmetic runs in the HIP kernels of
+libyolopost.so.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synthetic import YOLOV3_ANCHORS
+
+
+def _dims(inp_dim):
+    if isinstance(inp_dim, (tuple, list)):
+        return int(inp_dim[0]), int(inp_dim[1])          # (H, W)
+    return int(inp_dim), int(inp_dim)
+
+
+def _scaled_anchors(anchors, sx, sy):
+    """float32(anchor_px / stride), the division carried out in double (the tutorial divides
+    Python numbers and then builds a FloatTensor)."""
+    a = np.asarray(anchors, dtype=np.float64).reshape(-1, 2)
+    return [(float(np.float32(w / sx)), float(np.float32(h / sy))) for w, h in a]
+
+
+def _head_desc(t, inp_dim, anchors, num_classes):
+    in_h, in_w = _dims(inp_dim)
+    if t.dim() != 4:
+        raise ValueError("a detection head must be (B, A*(5+C), grid_h, grid_w)")
+    B, ch, gh, gw = t.shape
+    A = len(anchors)
+    if ch != A * (5 + num_classes):
+        raise ValueError("head has %d channels, expected %d anchors x (5 + %d classes)"
+                         % (ch, A, num_classes))
+    sx, sy = in_w // gw, in_h // gh
+    if sx <= 0 or sy <= 0:
+        raise ValueError("grid larger than the input size")
+    return _lib.make_head(t, gh, gw, _scaled_anchors(anchors, sx, sy), sx, sy)
+
+
+def predict_transform(prediction, inp_dim, anchors, num_classes, CUDA=True):
+    """One NCHW detection head (B, A*(5+C), G, G) -> decoded rows (B, G*G*A, 5+C):
+    [cx, cy, w, h, objectness, class scores] in input pixels.  ``inp_dim`` is an int or
+    (H, W); ``anchors`` are pixel (w, h) pairs.  The input is not modified."""
+    t = _lib.as_f32(prediction, "prediction")
+    return predict_transform_heads([t], inp_dim, [anchors], num_classes)
+
+
+def predict_transform_heads(heads, inp_dim, anchors_per_head, num_classes):
+    """All heads in ONE launch; equals torch.cat of the per-head results along dim 1."""
+    heads = [_lib.as_f32(h, "heads[%d]" % i) for i, h in enumerate(heads)]
+    if not 1 <= len(heads) <= _lib.YP_MAX_HEADS:
+        raise ValueError("1..%d heads supported" % _lib.YP_MAX_HEADS)
+    dev = heads[0].device
+    B = heads[0].shape[0]
+    descs = (_lib.YpHead * len(heads))(
+        *[_head_desc(h, inp_dim, a, num_classes) for h, a in zip(heads, anchors_per_head)])
+    N = sum(d.grid_h * d.grid_w * d.num_anchors for d in descs)
+    rows = torch.empty((B, N, 5 + num_classes), dtype=torch.float32, device=dev)
+    if B == 0:
+        return rows
+    with torch.cuda.device(dev):
+        rc = _lib.load().yp_predict_transform_yolov3(descs, len(heads), B, num_classes,
+                                                     rows.data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "yp_predict_transform_yolov3")
+    return rows
+
+
+def _v3_params(batch, num_classes, confidence, nms_conf, batch_offset=0):
+    p = _lib.YpParams()
+    p.mode = _lib.YP_MODE_YOLOV3
+    p.batch = int(batch)
+    p.num_classes = int(num_classes)
+    p.max_out = 0
+    p.conf_thr = float(confidence)
+    p.nms_thr = float(nms_conf)
+    p.batch_offset = int(batch_offset)
+    return p
+
+
+def write_results_device(prediction, confidence, num_classes, nms_conf=0.4, out_cap=None,
+                         want_stats=False):
+    """write_results without the host synchronisation: returns (rows (cap, 8), count (1,)
+    int32, stats or None), all on the device; rows[:count] are the detections."""
+    pred = _lib.as_f32(prediction, "prediction")
+    if pred.dim() != 3 or pred.shape[2] != 5 + num_classes:
+        raise ValueError("prediction must be (B, N, 5 + num_classes)")
+    B, N, _ = pred.shape
+    dev = pred.device
+    cap = B * N if out_cap is None else int(out_cap)
+    out = torch.empty((max(cap, 1), 8), dtype=torch.float32, device=dev)
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    stats = torch.zeros((3, B, num_classes), dtype=torch.int32, device=dev) if want_stats else None
+    if B == 0 or N == 0:
+        return out, count, stats
+    L = _lib.load()
+    p = _v3_params(B, num_classes, confidence, nms_conf)
+    ws = _lib.workspace(L.yp_rows_workspace_bytes(B, N, num_classes), dev)
+    with torch.cuda.device(dev):
+        rc = L.yp_write_results(pred.data_ptr(), N, ctypes.byref(p), out.data_ptr(), cap,
+                                count.data_ptr(), stats.data_ptr() if want_stats else None,
+                                ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "yp_write_results")
+    return out, count, stats
+
+
+def write_results(prediction, confidence, num_classes, nms_conf=0.4):
+    """Decoded rows (B, N, 5+C) -> detections (D, 8)
+    [image, x1, y1, x2, y2, objectness, class score, class id], ordered by image, class id,
+    objectness descending; the int 0 when nothing survives (as the tutorial returns)."""
+    out, count, _ = write_results_device(prediction, confidence, num_classes, nms_conf)
+    d = int(count.item())
+    if d == 0:
+        return 0
+    return out[:d]
+
+
+def bbox_iou(box1, box2):
+    """IoU (pixel-inclusive, +1 form) of box1 (1, >=4) with every row of box2 (M, >=4);
+    corners are the first four columns (x1, y1, x2, y2).  Returns (M,)."""
+    b1 = _lib.as_f32(box1, "box1").reshape(-1)
+    b2 = _lib.as_f32(box2, "box2")
+    if b2.dim() == 1:
+        b2 = b2.unsqueeze(0)
+    if b1.numel() < 4 or b2.shape[1] < 4:
+        raise ValueError("boxes need at least four columns")
+    M = b2.shape[0]
+    out = torch.empty((M,), dtype=torch.float32, device=b2.device)
+    if M == 0:
+        return out
+    with torch.cuda.device(b2.device):
+        rc = _lib.load().yp_bbox_iou(b1.data_ptr(), b2.data_ptr(), M, b2.shape[1], out.data_ptr(),
+                                     _lib.stream_ptr(b2.device))
+    _lib.check(rc, "yp_bbox_iou")
+    return out
+
+
+class YoloV3Post:
+    """Fused raw-heads -> detections engine for a fixed configuration.
+
+    Buffers (workspace, output rows, count, statistics) are allocated once; ``run`` only
+    enqueues three kernels on the current stream and returns device tensors, so it can sit
+    in a serving loop without host synchronisation.  ``batch_offset`` is added to the image
+    index in column 0 (used when a batch is sharded over several GPUs)."""
+
+    def __init__(self, batch, inp_dim, num_classes=5, confidence=0.5, nms_conf=0.4,
+                 anchors=YOLOV3_ANCHORS, strides=(32, 16, 8), device=None, out_cap=None,
+                 batch_offset=0):
+        self.device = torch.device(device if device is not None
+                                   else "cuda:%d" % torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise _lib.YoloPostError("YoloV3Post needs a ROCm device; there is no CPU path")
+        self.batch, self.inp_dim, self.num_classes = int(batch), inp_dim, int(num_classes)
+        self.anchors, self.strides = anchors, tuple(strides)
+        in_h, in_w = _dims(inp_dim)
+        self.grids = [(in_h // s, in_w // s) for s in self.strides]
+        self.rows_per_image = sum(gh * gw * len(a) for (gh, gw), a in zip(self.grids, anchors))
+        self.params = _v3_params(batch, num_classes, confidence, nms_conf, batch_offset)
+        self._lib = _lib.load()
+        shape_only = (_lib.YpHead * len(self.grids))(*[
+            _lib.make_head(None, gh, gw, _scaled_anchors(a, in_w // gw, in_h // gh),
+                           in_w // gw, in_h // gh)
+            for (gh, gw), a in zip(self.grids, anchors)])
+        nbytes = self._lib.yp_detect_yolov3_workspace_bytes(shape_only, len(self.grids),
+                                                            self.batch, self.num_classes)
+        if nbytes == 0:
+            raise _lib.YoloPostError("unsupported head geometry")
+        self.workspace = _lib.workspace(nbytes, self.device)
+        self.cap = self.batch * self.rows_per_image if out_cap is None else int(out_cap)
+        self.out = torch.empty((max(self.cap, 1), 8), dtype=torch.float32, device=self.device)
+        self.count = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        self.stats = torch.zeros((3, self.batch, self.num_classes), dtype=torch.int32,
+                                 device=self.device)
+
+    def _descs(self, heads):
+        if len(heads) != len(self.grids):
+            raise ValueError("expected %d heads" % len(self.grids))
+        hs = []
+        for h, (gh, gw), a in zip(heads, self.grids, self.anchors):
+            _lib.require_device(h, "head")
+            if h.dtype != torch.float32 or not h.is_contiguous():
+                raise ValueError("heads must be contiguous float32")
+            if tuple(h.shape) != (self.batch, len(a) * (5 + self.num_classes), gh, gw):
+                raise ValueError("head shape %r does not match the engine" % (tuple(h.shape),))
+            hs.append(_head_desc(h, self.inp_dim, a, self.num_classes))
+        return (_lib.YpHead * len(hs))(*hs)
+
+    def run(self, heads):
+        """Enqueue decode + filter + NMS; returns (rows (cap, 8), count (1,) int32) on the
+        device.  rows[:count] are valid once the stream has executed."""
+        descs = self._descs(heads)
+        with torch.cuda.device(self.device):
+            rc = self._lib.yp_detect_yolov3(
+                descs, len(descs), ctypes.byref(self.params), self.out.data_ptr(), self.cap,
+                self.count.data_ptr(), self.stats.data_ptr(), self.workspace.data_ptr(),
+                self.workspace.numel(), _lib.stream_ptr(self.device))
+        _lib.check(rc, "yp_detect_yolov3")
+        return self.out, self.count
+
+    def detect(self, heads):
+        """run() + one host read of the count: the (D, 8) detections (D may be 0)."""
+        out, count = self.run(heads)
+        d = min(int(count.item()), self.cap)
+        return out[:d]
+
+    def segment_stats(self):
+        """(survivors, kept, iou_pairs) per (image, class) of the last run, int32 (B, C)."""
+        s = self.stats.cpu().numpy()
+        return s[0], s[1], s[2]

@@ -1,0 +1,171 @@
+/*
+ * yolopost.h -- C ABI of libyolopost.so, the MI355X (gfx950) implementation of the YOLO
+ * detection post-processing path: anchor decode -> confidence filter -> greedy NMS.
+ *
+ * The reference (lbadams2/2D_object_detection) has no native or FFI layer: the path is a
+ * Python class of static methods, DetectNet in detect_net.py:75-183, called from
+ * train.py:128, :205 and :347-348.  Each entry point below names the Python function it
+ * replaces.  Two semantic modes exist:
+ *
+ *   YP_MODE_REFERENCE  detect_net.py exactly: one H x W grid, A anchors in grid units,
+ *                      memory order (b,row,col,anchor,attr), softmax class probabilities,
+ *                      score = objectness * class prob, filter score >= conf, boxes
+ *                      [y1,x1,y2,x2] scaled to (im_h, im_w), class-agnostic NMS that
+ *                      suppresses IoU > thr and keeps at most max_out boxes per image.
+ *   YP_MODE_YOLOV3     the three-stride YOLOv3 post-processing of the tutorial credited in
+ *                      README.md:1 (predict_transform / write_results / bbox_iou): NCHW
+ *                      heads, sigmoid class scores, filter objectness > conf, boxes
+ *                      [x1,y1,x2,y2] in input pixels, per-image per-class NMS ordered by
+ *                      objectness that keeps a later box only if IoU(+1 form) < thr.
+ *                      These functions are not present in the reference repository.
+ *
+ * Conventions
+ *   - every pointer named d_* or inside YpHead.data is DEVICE memory owned by the caller;
+ *     the library never allocates or frees device memory and never synchronises: kernels
+ *     are enqueued on `stream` (a hipStream_t passed as void*) and the call returns.
+ *   - return value: YP_OK (0), a negative YP_ERR_* argument error, or a positive
+ *     hipError_t from a failed launch.
+ *   - workspace: caller-allocated device scratch, 256-byte aligned, at least the size the
+ *     matching *_workspace_bytes function returns.  Calls that share a workspace must be
+ *     ordered on one stream.
+ *   - all arithmetic is IEEE binary32 without contraction; exp is the fixed sequence of
+ *     floor/fma/mul/add operations documented in csrc/yp_math.h, so results are
+ *     reproducible bit for bit.
+ */
+#ifndef YOLOPOST_H
+#define YOLOPOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YP_MAX_HEADS 4
+#define YP_MAX_ANCHORS 8
+
+enum { YP_MODE_YOLOV3 = 0, YP_MODE_REFERENCE = 1 };
+
+enum {
+    YP_OK = 0,
+    YP_ERR_ARG = -1,        /* null pointer, non-positive size, value out of range */
+    YP_ERR_WORKSPACE = -2,  /* workspace missing, misaligned or too small */
+    YP_ERR_UNSUPPORTED = -3 /* shape beyond the compiled limits (heads, anchors, sizes) */
+};
+
+/* One detection head.
+ * YP_MODE_YOLOV3:    data is NCHW (B, A*(5+C), grid_h, grid_w); anchors[] holds
+ *                    float32(anchor_px / stride) pairs (w,h); stride_x/stride_y are the
+ *                    pixel strides (input_w / grid_w, input_h / grid_h).
+ * YP_MODE_REFERENCE: data is (B, grid_h*grid_w*A*(5+C)) in memory order
+ *                    (b,row,col,anchor,attr) (detect_net.py:153); anchors[] holds
+ *                    params.YOLO_ANCHORS (w,h) in grid units (params.py:20-22); strides are
+ *                    ignored. */
+typedef struct YpHead {
+    const float *data;
+    int32_t grid_h;
+    int32_t grid_w;
+    int32_t num_anchors;
+    int32_t reserved;
+    float stride_x;
+    float stride_y;
+    float anchors[2 * YP_MAX_ANCHORS];
+} YpHead;
+
+/* Thresholds and sizes (params.py:9-10,15,27-28,31 in YP_MODE_REFERENCE). */
+typedef struct YpParams {
+    int32_t mode;         /* YP_MODE_* */
+    int32_t batch;        /* B */
+    int32_t num_classes;  /* C */
+    int32_t max_out;      /* per-image cap (params.max_boxes); <= 0 means unlimited */
+    float conf_thr;       /* params.object_conf / `confidence` */
+    float nms_thr;        /* params.nms_conf / `nms_conf` */
+    float im_h;           /* YP_MODE_REFERENCE: params.im_height */
+    float im_w;           /* YP_MODE_REFERENCE: params.im_width */
+    int32_t batch_offset; /* YP_MODE_YOLOV3: added to the image index written in column 0 */
+    int32_t reserved;
+} YpParams;
+
+int yp_version(void);
+const char *yp_strerror(int code);
+
+/* ---- decode only ------------------------------------------------------------------ */
+
+/* Replaces DetectNet.predict_transform, detect_net.py:152-183.
+ * d_pred (B, H*W*A*(5+C)) -> d_center (B,H,W,A,2), d_wh (B,H,W,A,2), d_obj (B,H,W,A,1),
+ * d_cls (B,H,W,A,C).  anchors: HOST pointer to A (w,h) pairs. */
+int yp_predict_transform_reference(const float *d_pred, int batch, int grid_h, int grid_w,
+                                   int num_anchors, int num_classes, const float *anchors,
+                                   float *d_center, float *d_wh, float *d_obj, float *d_cls,
+                                   void *stream);
+
+/* YOLOv3 predict_transform for 1..YP_MAX_HEADS heads in ONE launch (not in the reference;
+ * see the mode note above).  Output rows (B, N, 5+C), N = sum_h gh*gw*A, heads
+ * concatenated in array order, row index inside a head (row*gw+col)*A + a, row =
+ * [cx, cy, w, h, objectness, class scores]. */
+int yp_predict_transform_yolov3(const YpHead *heads, int n_heads, int batch, int num_classes,
+                                float *d_rows, void *stream);
+
+/* ---- whole path from raw heads (decode + filter + NMS fused) ------------------------- */
+
+size_t yp_detect_yolov3_workspace_bytes(const YpHead *heads, int n_heads, int batch,
+                                        int num_classes);
+
+/* YOLOv3 path from raw heads: the composition predict_transform + write_results without
+ * materialising the decoded rows.
+ *   d_out_rows  (out_cap, 8) [image, x1, y1, x2, y2, objectness, class score, class id],
+ *               ordered by image, class id ascending, objectness descending
+ *   d_out_count [1] total detections D (rows beyond out_cap are not stored)
+ *   d_stats     optional [3*B*C] int32: survivors, kept, IoU pairs evaluated (low 32 bits)
+ *               per (image, class) segment; may be NULL */
+int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params,
+                     float *d_out_rows, int64_t out_cap, int32_t *d_out_count,
+                     int32_t *d_stats, void *d_workspace, size_t workspace_bytes,
+                     void *stream);
+
+size_t yp_detect_reference_workspace_bytes(int batch, int grid_h, int grid_w, int num_anchors);
+
+/* Replaces the composition run_validation uses, train.py:347-348:
+ * DetectNet.filter_boxes(DetectNet.predict_transform(pred)), detect_net.py:90-183.
+ * Outputs are padded to max_out rows per image:
+ *   d_out_boxes (B,max_out,4) [y1,x1,y2,x2] pixels, d_out_scores (B,max_out),
+ *   d_out_classes (B,max_out) int32, d_out_index (B,max_out) int32 = position in the
+ *   image's compacted survivor list (the reference's nms_indexes, detect_net.py:136,144),
+ *   d_out_counts (B) rows used, d_surv_counts (B) survivors of the >= filter. */
+int yp_detect_reference(const YpHead *head, const YpParams *params, float *d_out_boxes,
+                        float *d_out_scores, int32_t *d_out_classes, int32_t *d_out_index,
+                        int32_t *d_out_counts, int32_t *d_surv_counts, void *d_workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* ---- filter + NMS on already decoded tensors ----------------------------------------- */
+
+/* segments_per_image: num_classes for yp_write_results, 1 for the reference-mode entries. */
+size_t yp_rows_workspace_bytes(int batch, int rows_per_image, int segments_per_image);
+
+/* YOLOv3 write_results on decoded rows (B, N, 5+C) (not in the reference; mode note
+ * above).  Outputs as yp_detect_yolov3.  d_rows is not modified. */
+int yp_write_results(const float *d_rows, int rows_per_image, const YpParams *params,
+                     float *d_out_rows, int64_t out_cap, int32_t *d_out_count,
+                     int32_t *d_stats, void *d_workspace, size_t workspace_bytes,
+                     void *stream);
+
+/* Replaces DetectNet.filter_boxes, detect_net.py:90-146, on the 4-tuple returned by
+ * predict_transform; N = H*W*A rows per image.  Outputs as yp_detect_reference. */
+int yp_filter_boxes_reference(const float *d_center, const float *d_wh, const float *d_obj,
+                              const float *d_cls, int rows_per_image, const YpParams *params,
+                              float *d_out_boxes, float *d_out_scores, int32_t *d_out_classes,
+                              int32_t *d_out_index, int32_t *d_out_counts,
+                              int32_t *d_surv_counts, void *d_workspace,
+                              size_t workspace_bytes, void *stream);
+
+/* YOLOv3 bbox_iou (not in the reference): IoU, pixel-inclusive (+1) form, of the single
+ * box d_box1[0..3] with M boxes whose corners are the first four floats of rows spaced
+ * row_stride floats apart. */
+int yp_bbox_iou(const float *d_box1, const float *d_boxes2, int m, int row_stride,
+                float *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOPOST_H */

@@ -1,0 +1,26 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a ROCm GPU (runs on the MI355X box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return importlib.import_module("2d_object_detection_amd")
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    return torch.device("cuda:0")

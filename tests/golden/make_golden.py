@@ -1,0 +1,100 @@
+"""Regenerates the committed golden vectors from the CPU oracle (oracle/ypo.c, SPEC exp
+flavour) and cross-checks them with the independent numpy restatement before writing.
+
+    python tests/golden/make_golden.py
+
+The reference cannot be imported (TensorFlow is absent), so these vectors pin the oracle
+and the HIP path to each other, not to a run of the reference itself."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import oracle  # noqa: E402
+from oracle import np_oracle as npo  # noqa: E402
+
+syn = importlib.import_module("2d_object_detection_amd.synthetic")
+ANCHORS_R = np.array(((0.57273, 0.677385), (1.87446, 2.06253), (3.33843, 5.47434),
+                      (7.88282, 3.52778), (9.77052, 9.16828)))
+
+
+def rel(a, b):
+    return float((np.abs(a - b) / np.maximum(np.abs(b), 1e-30)).max()) if a.size else 0.0
+
+
+def golden_reference_mode():
+    pred = syn.make_reference_head(3, seed=101).numpy()
+    c, w, o, p = oracle.r_predict_transform(pred, 13, 13, 5, 5, ANCHORS_R)
+    n = npo.r_predict_transform(pred, 13, 13, 5, 5, ANCHORS_R)
+    assert max(rel(a, b) for a, b in zip((c, w, o, p), n)) < 1e-5
+    boxes, scores, classes, index, surv = oracle.r_filter_boxes(c, w, o, p, 0.6, 0.5, 20, 1280, 1920)
+    alt = npo.r_filter_boxes(c, w, o, p, 0.6, 0.5, 20, 1280, 1920)
+    for k, got in enumerate((boxes, scores, classes, index)):
+        for b in range(3):
+            assert np.array_equal(got[b], alt[k][b])
+    counts = np.array([len(s) for s in scores], np.int32)
+    np.savez_compressed(
+        os.path.join(HERE, "reference_13x13.npz"), pred=pred, center=c, wh=w, obj=o, cls=p,
+        boxes=np.concatenate(boxes), scores=np.concatenate(scores),
+        classes=np.concatenate(classes), index=np.concatenate(index), counts=counts, surv=surv,
+        conf=np.float32(0.6), nms=np.float32(0.5), max_boxes=np.int32(20))
+
+
+def golden_yolov3_mode():
+    heads = [h.numpy() for h in syn.make_heads(2, 96, num_classes=5, seed=202, clustered=True,
+                                               n_objects=4)]
+    rows = np.concatenate([oracle.n_predict_transform(h, 96, a, 5)
+                           for h, a in zip(heads, syn.YOLOV3_ANCHORS)], 1)
+    rows_np = np.concatenate([npo.n_predict_transform(h, 96, a, 5)
+                              for h, a in zip(heads, syn.YOLOV3_ANCHORS)], 1)
+    assert rel(rows, rows_np) < 1e-5
+    det, surv, pairs = oracle.n_write_results(rows, 0.5, 5, 0.4)
+    assert np.array_equal(det, npo.n_write_results(rows, 0.5, 5, 0.4))
+    assert 0 < det.shape[0] < surv.sum()          # NMS really suppresses something
+    np.savez_compressed(os.path.join(HERE, "yolov3_96.npz"), head0=heads[0], head1=heads[1],
+                        head2=heads[2], rows=rows, det=det, surv=surv,
+                        conf=np.float32(0.5), nms=np.float32(0.4))
+
+
+def golden_nms_edge_cases():
+    """Hand-built decoded rows: ties, IoU exactly at the threshold, degenerate boxes."""
+    C = 3
+
+    def row(cx, cy, w, h, obj, cls):
+        r = [cx, cy, w, h, obj] + [0.1] * C
+        r[5 + cls] = 0.9
+        return r
+    rows = np.array([[
+        row(10, 10, 9, 9, 0.9, 0), row(10, 10, 9, 9, 0.9, 0),
+        row(100, 100, 1, 1, 0.8, 0), row(101, 100, 1, 1, 0.8, 0),
+        row(200, 200, 0, 0, 0.7, 1), row(200, 200, 0, 0, 0.7, 1),
+        row(300, 300, -4, -4, 0.6, 1), row(300, 300, -4, -4, 0.95, 1),
+        row(50, 50, 3, 3, 0.5, 2), row(60, 60, 3, 3, 0.0, 2), row(70, 70, 3, 3, 0.50000006, 2),
+    ]], np.float32)
+    out = {}
+    for name, thr in (("t04", 0.4), ("t13", 1.0 / 3.0), ("t05", 0.5), ("t10", 1.0)):
+        det, _, _ = oracle.n_write_results(rows, 0.5, C, thr)
+        assert np.array_equal(det, npo.n_write_results(rows, 0.5, C, thr))
+        out["det_" + name] = det
+    # boxes [0,0,2,1] / [1,0,3,1]: IoU (no +1) = 1/3 ; [0,0,1,1] / [0,0,1,2]: IoU = 0.5
+    tf_boxes = np.array([[0, 0, 1, 2], [0, 1, 1, 3], [0, 0, 1, 1], [0, 0, 2, 1], [5, 5, 5, 9],
+                         [1, 1, 0, 0]], np.float32)
+    tf_scores = np.array([0.9, 0.9, 0.8, 0.8, 0.7, 0.95], np.float32)
+    for name, thr in (("third", 1.0 / 3.0), ("half", 0.5), ("low", 0.3)):
+        sel = oracle.tf_nms(tf_boxes, tf_scores, 10, thr)
+        assert np.array_equal(sel, npo.tf_nms(tf_boxes, tf_scores, 10, thr))
+        out["tf_" + name] = sel
+    np.savez_compressed(os.path.join(HERE, "nms_edge_cases.npz"), rows=rows, tf_boxes=tf_boxes,
+                        tf_scores=tf_scores, **out)
+
+
+if __name__ == "__main__":
+    golden_reference_mode()
+    golden_yolov3_mode()
+    golden_nms_edge_cases()
+    print("golden vectors written to", HERE)

@@ -1,0 +1,88 @@
+"""Multi-rank logic on the CPU: batch sharding and the variable-length all-gather over the
+gloo backend with world_size 2 (the GPU path uses the same code over nccl/RCCL), plus the
+property that per-shard oracle results concatenate to the unsharded result."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = importlib.import_module("2d_object_detection_amd.distributed")
+    try:
+        # rank r contributes r*3+1 rows, the first column carries the rank
+        n = rank * 3 + 1
+        rows = torch.full((10, 8), float(rank))
+        rows[:, 1] = torch.arange(10, dtype=torch.float32)
+        got, counts = d.all_gather_rows(rows, n)
+        want = torch.cat([torch.cat([torch.full((r * 3 + 1, 1), float(r)),
+                                     torch.arange(r * 3 + 1, dtype=torch.float32).view(-1, 1)], 1)
+                          for r in range(world)])
+        ok = counts == [r * 3 + 1 for r in range(world)] and torch.equal(got[:, :2], want)
+        # a rank with zero rows, and everybody empty
+        got2, c2 = d.all_gather_rows(rows, 0 if rank == 0 else 2)
+        ok = ok and c2 == [0] + [2] * (world - 1) and got2.shape[0] == 2 * (world - 1)
+        got3, c3 = d.all_gather_rows(rows, 0)
+        ok = ok and got3.shape == (0, 8) and c3 == [0] * world
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_rows_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
+
+
+def test_shard_bounds_cover_the_batch():
+    d = importlib.import_module("2d_object_detection_amd.distributed")
+    for batch in (1, 7, 64, 512):
+        for world in (1, 2, 3, 8):
+            spans = [d.shard_bounds(batch, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == batch
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_sharded_oracle_concatenates_to_unsharded():
+    """Images are independent: running each shard separately (with the image index offset
+    to global numbering) and concatenating equals the unsharded run."""
+    syn = importlib.import_module("2d_object_detection_amd.synthetic")
+    d = importlib.import_module("2d_object_detection_amd.distributed")
+    heads = [h.numpy() for h in syn.make_heads(5, 96, seed=3, clustered=True, n_objects=4)]
+    full, _, _ = oracle.n_detect(heads, 96, syn.YOLOV3_ANCHORS, 5, 0.5, 0.4)
+    parts = []
+    for r in range(2):
+        lo, hi = d.shard_bounds(5, 2, r)
+        part, _, _ = oracle.n_detect([h[lo:hi] for h in heads], 96, syn.YOLOV3_ANCHORS, 5, 0.5, 0.4)
+        part = part.copy()
+        part[:, 0] += lo
+        parts.append(part)
+    assert np.array_equal(np.concatenate(parts), full)

@@ -1,0 +1,321 @@
+"""GPU parity: the HIP path (through the C ABI of libyolopost.so) against the CPU oracle.
+
+Bars: kept-box indices, class ids, counts and ordering are bit-exact; decoded floating
+point values are bit-exact against the oracle's SPEC exp flavour (same binary32 operation
+sequence on both sides) and within 1e-5 relative of the libm flavour and of the independent
+numpy restatement.  The reference itself (TensorFlow) cannot run here, so these are the
+pins documented in oracle/ypo.c ("parity unpinned" against the real reference)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import np_oracle as npo
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5  # tolerance named by the task for box coordinates / scores
+
+
+def rel_err(a, b):
+    return float((np.abs(a - b) / np.maximum(np.abs(b), 1e-30)).max()) if a.size else 0.0
+
+
+def v3_oracle(heads, inp_dim, anchors, C, conf, nms, flavour=oracle.SPEC):
+    return oracle.n_detect([h.numpy() for h in heads], inp_dim, anchors, C, conf, nms, flavour)
+
+
+# ------------------------------------------------------------------ YOLOv3 mode, decode
+
+@pytest.mark.parametrize("inp_dim,B,C,seed", [(416, 2, 5, 0), (608, 1, 5, 1), ((320, 480), 2, 5, 2),
+                                              (416, 1, 80, 3), (96, 3, 1, 4)])
+def test_v3_predict_transform_matches_oracle(pkg, dev, inp_dim, B, C, seed):
+    syn, util = pkg.synthetic, pkg.util
+    heads = syn.make_heads(B, inp_dim, num_classes=C, seed=seed)
+    per_head = [util.predict_transform(h.to(dev), inp_dim, a, C).cpu().numpy()
+                for h, a in zip(heads, syn.YOLOV3_ANCHORS)]
+    fused = util.predict_transform_heads([h.to(dev) for h in heads], inp_dim,
+                                         syn.YOLOV3_ANCHORS, C).cpu().numpy()
+    assert np.array_equal(np.concatenate(per_head, 1), fused)
+    for h, a, got in zip(heads, syn.YOLOV3_ANCHORS, per_head):
+        want = oracle.n_predict_transform(h.numpy(), inp_dim, a, C, oracle.SPEC)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want)                       # same op sequence: bit-exact
+        assert rel_err(got, oracle.n_predict_transform(h.numpy(), inp_dim, a, C, oracle.LIBM)) < REL
+        assert rel_err(got, npo.n_predict_transform(h.numpy(), inp_dim, a, C)) < REL
+
+
+def test_v3_predict_transform_extreme_logits(pkg, dev):
+    """exp overflow/underflow, signed zeros and huge logits decode exactly like the oracle."""
+    syn, util = pkg.synthetic, pkg.util
+    C = 5
+    h = syn.make_heads(1, 416, num_classes=C, seed=9)[2]
+    flat = h.view(-1)
+    specials = torch.tensor([0.0, -0.0, 88.7, 88.73, 100.0, -87.0, -100.0, -103.9, -104.5, -200.0,
+                             1e-30, -1e-30, 30.0, -30.0, 16.7, -16.7])
+    flat[:specials.numel()] = specials
+    flat[5000:5000 + specials.numel()] = specials
+    got = util.predict_transform(h.to(dev), 416, syn.YOLOV3_ANCHORS[2], C).cpu().numpy()
+    want = oracle.n_predict_transform(h.numpy(), 416, syn.YOLOV3_ANCHORS[2], C, oracle.SPEC)
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+# ---------------------------------------------------------------- YOLOv3 mode, whole path
+
+@pytest.mark.parametrize("inp_dim,B,C,conf,nms,seed,clustered", [
+    (416, 1, 5, 0.5, 0.4, 0, False),          # BASELINE config 1
+    (416, 4, 5, 0.5, 0.4, 1, False),
+    (416, 3, 5, 0.5, 0.4, 11, True),          # overlapping boxes: NMS actually suppresses
+    (608, 2, 5, 0.5, 0.4, 3, True),
+    ((320, 480), 2, 5, 0.3, 0.4, 2, True),    # rectangular grid
+    (416, 2, 80, 0.5, 0.45, 5, True),         # dynamic class count
+    (416, 2, 5, 0.001, 0.4, 4, False),        # near-all survive: segments beyond the LDS sort
+    (416, 1, 5, 0.999999, 0.4, 6, False),     # nothing survives
+])
+def test_v3_detect_matches_oracle(pkg, dev, inp_dim, B, C, conf, nms, seed, clustered):
+    syn, util = pkg.synthetic, pkg.util
+    heads = syn.make_heads(B, inp_dim, num_classes=C, seed=seed, clustered=clustered)
+    want, surv, _ = v3_oracle(heads, inp_dim, syn.YOLOV3_ANCHORS, C, conf, nms)
+    eng = util.YoloV3Post(B, inp_dim, C, conf, nms, device=dev)
+    dheads = [h.to(dev) for h in heads]
+    got = eng.detect(dheads).cpu().numpy()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.array_equal(got, want)
+    s_surv, s_kept, _ = eng.segment_stats()
+    assert np.array_equal(s_surv.sum(1), surv)
+    assert int(s_kept.sum()) == want.shape[0]
+    # second run on the same buffers: deterministic, no stale state
+    got2 = eng.detect(dheads).cpu().numpy()
+    assert np.array_equal(got2, got)
+    # the unfused drop-in composition gives the same rows
+    rows = util.predict_transform_heads(dheads, inp_dim, syn.YOLOV3_ANCHORS, C)
+    res = util.write_results(rows, conf, C, nms)
+    if want.shape[0] == 0:
+        assert isinstance(res, int) and res == 0
+    else:
+        assert np.array_equal(res.cpu().numpy(), want)
+
+
+def test_v3_detect_vs_libm_oracle_reports_ties(pkg, dev):
+    """Against the libm-exp oracle values agree to 1e-5 and the kept sets are identical
+    unless an objectness or IoU lands within an ulp of its threshold; any such difference is
+    reported (printed) rather than hidden."""
+    syn, util = pkg.synthetic, pkg.util
+    heads = syn.make_heads(4, 416, seed=21, clustered=True)
+    want, _, _ = v3_oracle(heads, 416, syn.YOLOV3_ANCHORS, 5, 0.5, 0.4, oracle.LIBM)
+    got = util.YoloV3Post(4, 416, 5, 0.5, 0.4, device=dev).detect([h.to(dev) for h in heads])
+    got = got.cpu().numpy()
+    if got.shape != want.shape:
+        print("tie report: GPU kept %d rows, libm oracle kept %d" % (got.shape[0], want.shape[0]))
+        pytest.xfail("keep sets differ at a threshold tie (reported above)")
+    assert np.array_equal(got[:, [0, 7]], want[:, [0, 7]])
+    assert rel_err(got[:, 1:7], want[:, 1:7]) < REL
+
+
+def test_v3_write_results_on_oracle_rows_bit_exact(pkg, dev):
+    """NMS fed the ORACLE's decoded rows (identical inputs on both sides): every output bit
+    and every kept index must match."""
+    syn, util = pkg.synthetic, pkg.util
+    heads = syn.make_heads(3, 416, seed=5, clustered=True)
+    rows = np.concatenate([oracle.n_predict_transform(h.numpy(), 416, a, 5, oracle.LIBM)
+                           for h, a in zip(heads, syn.YOLOV3_ANCHORS)], 1)
+    want, _, _ = oracle.n_write_results(rows, 0.5, 5, 0.4)
+    before = rows.copy()
+    d_rows = torch.from_numpy(rows).to(dev)
+    got = util.write_results(d_rows, 0.5, 5, 0.4).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.array_equal(d_rows.cpu().numpy(), before)         # input not modified
+    small = npo.n_write_results(rows[:1, :3000], 0.5, 5, 0.4)   # independent restatement
+    got_small = util.write_results(d_rows[:1, :3000].contiguous(), 0.5, 5, 0.4).cpu().numpy()
+    assert np.array_equal(got_small, small)
+
+
+def test_v3_ties_thresholds_and_degenerate_boxes(pkg, dev):
+    """Constructed rows: equal objectness (order by anchor index), IoU exactly at the
+    threshold (kept only if IoU < thr), zero-size and inverted boxes, objectness exactly at
+    the confidence (strict >), exact zero objectness."""
+    util = pkg.util
+    C = 3
+
+    def row(cx, cy, w, h, obj, cls):
+        r = [cx, cy, w, h, obj] + [0.1] * C
+        r[5 + cls] = 0.9
+        return r
+    rows = [
+        row(10, 10, 9, 9, 0.9, 0),      # box [5.5,5.5,14.5,14.5]
+        row(10, 10, 9, 9, 0.9, 0),      # identical, same score: later index suppressed
+        row(100, 100, 1, 1, 0.8, 0),    # IoU(+1) with next = (2*1... checked by oracle)
+        row(101, 100, 1, 1, 0.8, 0),
+        row(200, 200, 0, 0, 0.7, 1),    # zero-size box (area 1 with the +1 form)
+        row(200, 200, 0, 0, 0.7, 1),
+        row(300, 300, -4, -4, 0.6, 1),  # inverted corners
+        row(300, 300, -4, -4, 0.95, 1),
+        row(50, 50, 3, 3, 0.5, 2),      # objectness == confidence: dropped (strict >)
+        row(60, 60, 3, 3, 0.0, 2),      # exact zero
+        row(70, 70, 3, 3, 0.50000006, 2),
+    ]
+    pred = np.array([rows, rows[::-1]], np.float32)
+    for nms in (0.4, 1.0 / 3.0, 0.5, 1.0):
+        want, _, _ = oracle.n_write_results(pred, 0.5, C, nms)
+        got = util.write_results(torch.from_numpy(pred).to(dev), 0.5, C, nms).cpu().numpy()
+        assert np.array_equal(got, want), nms
+        assert np.array_equal(npo.n_write_results(pred, 0.5, C, nms), want), nms
+
+
+def test_v3_empty_result_returns_zero(pkg, dev):
+    util = pkg.util
+    pred = torch.zeros((2, 100, 10), device=dev)
+    assert util.write_results(pred, 0.5, 5) == 0
+
+
+def test_v3_output_capacity_is_respected(pkg, dev):
+    syn, util = pkg.synthetic, pkg.util
+    heads = syn.make_heads(2, 416, seed=8)
+    want, _, _ = v3_oracle(heads, 416, syn.YOLOV3_ANCHORS, 5, 0.5, 0.4)
+    cap = want.shape[0] // 2
+    eng = util.YoloV3Post(2, 416, 5, 0.5, 0.4, device=dev, out_cap=cap)
+    guard = torch.full((16, 8), -7.0, device=dev)
+    out, count = eng.run([h.to(dev) for h in heads])
+    assert int(count.item()) == want.shape[0]                  # true total is still reported
+    assert np.array_equal(out[:cap].cpu().numpy(), want[:cap])
+    assert float(guard.min()) == -7.0
+
+
+def test_v3_bbox_iou_matches_oracle(pkg, dev):
+    util = pkg.util
+    g = torch.Generator().manual_seed(0)
+    xy = torch.rand(500, 2, generator=g) * 400
+    wh = torch.rand(500, 2, generator=g) * 80
+    boxes = torch.cat([xy, xy + wh, torch.rand(500, 3, generator=g)], 1)
+    boxes[7] = boxes[0]
+    got = util.bbox_iou(boxes[0:1].to(dev), boxes.to(dev)).cpu().numpy()
+    want = oracle.n_bbox_iou(boxes[0].numpy(), boxes.numpy())
+    assert np.array_equal(got, want)
+    assert got[0] == 1.0 and got[7] == 1.0
+
+
+# ------------------------------------------------------------------------ reference mode
+
+def ref_oracle(pred, P, flavour=oracle.SPEC):
+    return oracle.r_detect(pred, P.grid_height, P.grid_width, P.num_anchors, P.num_classes,
+                           np.asarray(P.YOLO_ANCHORS), P.object_conf, P.nms_conf, P.max_boxes,
+                           P.im_height, P.im_width, flavour)
+
+
+def assert_ref_equal(got, want, B):
+    boxes, scores, classes, index = got
+    ob, os_, oc, oi, _ = want
+    for b in range(B):
+        assert np.array_equal(np.asarray(boxes[b], np.float32).reshape(-1, 4), ob[b])
+        assert np.array_equal(np.asarray(scores[b], np.float32), os_[b])
+        assert np.array_equal(np.asarray(classes[b]), oc[b])
+        assert np.asarray(classes[b]).dtype == np.int64
+        assert np.array_equal(np.asarray(index[b]), oi[b])
+
+
+@pytest.mark.parametrize("B,seed,relu", [(16, 0, False), (16, 1, True), (1, 2, False), (5, 3, False)])
+def test_ref_predict_transform_and_filter_boxes(pkg, dev, B, seed, relu):
+    P, DN = pkg.params, pkg.DetectNet
+    pred = pkg.synthetic.make_reference_head(B, seed=seed, relu=relu)
+    c, w, o, p = DN.predict_transform(pred.to(dev))
+    oc_, ow, oo, op = oracle.r_predict_transform(pred.numpy(), 13, 13, 5, 5, P.YOLO_ANCHORS)
+    assert tuple(c.shape) == (B, 13, 13, 5, 2) and tuple(p.shape) == (B, 13, 13, 5, 5)
+    assert tuple(o.shape) == (B, 13, 13, 5, 1)
+    for got, want in ((c, oc_), (w, ow), (o, oo), (p, op)):
+        assert np.array_equal(got.cpu().numpy(), want)
+    nc, nw, no, npp = npo.r_predict_transform(pred.numpy(), 13, 13, 5, 5, P.YOLO_ANCHORS)
+    for got, want in ((c, nc), (w, nw), (o, no), (p, npp)):
+        assert rel_err(got.cpu().numpy(), want) < REL
+    want = ref_oracle(pred.numpy(), P)
+    assert_ref_equal(DN.filter_boxes((c, w, o, p)), want, B)
+    assert_ref_equal(DN.detect(pred.to(dev)), want, B)           # fused path, same answer
+    assert np.array_equal(DN.last_survivor_counts.cpu().numpy(), want[4])
+
+
+def test_ref_all_zero_head_known_answer(pkg, dev):
+    """Hand-derivable: all-zero head -> centre ((c+.5)/13, (r+.5)/13), wh = anchors/13,
+    obj .5, class probs .2, score .1 < .6 -> four empty outputs with .size == 0."""
+    P, DN = pkg.params, pkg.DetectNet
+    pred = torch.zeros((3, 13 * 13 * 5 * 10), device=dev)
+    c, w, o, p = DN.predict_transform(pred)
+    c, w = c.cpu().numpy(), w.cpu().numpy()
+    rr, cc = np.meshgrid(np.arange(13), np.arange(13), indexing="ij")
+    assert np.allclose(c[0, :, :, 0, 0], (cc + 0.5) / 13, rtol=1e-6)
+    assert np.allclose(c[0, :, :, 0, 1], (rr + 0.5) / 13, rtol=1e-6)
+    assert np.allclose(w[1, 4, 7], np.asarray(P.YOLO_ANCHORS) / 13, rtol=1e-6)
+    assert np.all(o.cpu().numpy() == 0.5)
+    assert np.allclose(p.cpu().numpy(), 0.2, rtol=1e-6)
+    boxes, scores, classes, index = DN.filter_boxes(DN.predict_transform(pred))
+    assert boxes.size == 0 and scores.size == 0 and classes.size == 0 and index.size == 0
+    assert boxes.shape == (3, 0, 4)
+
+
+def test_ref_params_are_read_at_call_time(pkg, dev, monkeypatch):
+    P, DN = pkg.params, pkg.DetectNet
+    pred = pkg.synthetic.make_reference_head(4, seed=12)
+    for conf, nms, mb in ((0.3, 0.5, 20), (0.6, 0.2, 5), (0.9, 0.9, 1)):
+        monkeypatch.setattr(P, "object_conf", conf)
+        monkeypatch.setattr(P, "nms_conf", nms)
+        monkeypatch.setattr(P, "max_boxes", mb)
+        assert_ref_equal(DN.detect(pred.to(dev)), ref_oracle(pred.numpy(), P), 4)
+
+
+def test_ref_non_square_grid_reproduces_reference_indexing(pkg, dev, monkeypatch):
+    """On a non-square grid the reference's index construction gives (k mod H, k div H) and
+    divides channel 0 by H (detect_net.py:155-168); the drop-in reproduces that literally."""
+    P, DN = pkg.params, pkg.DetectNet
+    monkeypatch.setattr(P, "grid_height", 7)
+    monkeypatch.setattr(P, "grid_width", 11)
+    pred = pkg.synthetic.make_reference_head(2, grid_h=7, grid_w=11, seed=4)
+    c, w, o, p = DN.predict_transform(pred.to(dev))
+    oc_, ow, oo, op = oracle.r_predict_transform(pred.numpy(), 7, 11, 5, 5, P.YOLO_ANCHORS)
+    assert np.array_equal(c.cpu().numpy(), oc_) and np.array_equal(w.cpu().numpy(), ow)
+    assert_ref_equal(DN.detect(pred.to(dev)), ref_oracle(pred.numpy(), P), 2)
+
+
+def test_ref_nms_ties_and_threshold(pkg, dev, monkeypatch):
+    """Decoded 4-tuples built by hand: equal scores (lower index wins), IoU exactly 0.5
+    (kept: the reference suppresses only IoU > thr), zero-area and flipped boxes, more
+    survivors than max_boxes."""
+    P, DN = pkg.params, pkg.DetectNet
+    monkeypatch.setattr(P, "grid_height", 1)
+    monkeypatch.setattr(P, "grid_width", 8)
+    monkeypatch.setattr(P, "num_anchors", 4)
+    N = 32
+    center = np.zeros((2, N, 2), np.float32)
+    wh = np.zeros((2, N, 2), np.float32)
+    obj = np.full((2, N, 1), 0.95, np.float32)
+    cls = np.full((2, N, 5), 0.0, np.float32)
+    cls[..., 2] = 1.0
+    g = np.random.RandomState(0)
+    center[0] = g.rand(N, 2) * 0.5 + 0.25
+    wh[0] = g.rand(N, 2) * 0.4
+    # image 1: pairs with IoU exactly 0.5 (unit box vs 1x2 box), duplicates, zero area
+    center[1, :, :] = 0.5
+    wh[1, :, :] = 0.0
+    center[1, 0] = (0.25, 0.25); wh[1, 0] = (0.5, 0.5)
+    center[1, 1] = (0.25, 0.5);  wh[1, 1] = (0.5, 1.0)     # contains box 0, IoU = 0.5
+    center[1, 2] = (0.25, 0.25); wh[1, 2] = (0.5, 0.5)     # duplicate of 0, same score
+    wh[1, 3] = (-0.5, -0.5); center[1, 3] = (0.25, 0.25)   # flipped corners of box 0
+    obj[1, 5:, 0] = np.linspace(0.94, 0.7, N - 5)
+    shape5 = lambda a, k: torch.from_numpy(a.reshape(2, 1, 8, 4, k)).to(dev)
+    tp = (shape5(center, 2), shape5(wh, 2), shape5(obj, 1), shape5(cls, 5))
+    for nms, mb in ((0.5, 20), (0.49, 20), (0.5, 3), (0.0, 40)):
+        monkeypatch.setattr(P, "nms_conf", nms)
+        monkeypatch.setattr(P, "max_boxes", mb)
+        want = oracle.r_filter_boxes(center, wh, obj, cls, P.object_conf, nms, mb, 1280, 1920)
+        assert_ref_equal(DN.filter_boxes(tp), want, 2)
+        alt = npo.r_filter_boxes(center.reshape(2, N, 2), wh.reshape(2, N, 2), obj.reshape(2, N, 1),
+                                 cls.reshape(2, N, 5), P.object_conf, nms, mb, 1280, 1920)
+        for k in range(4):
+            for b in range(2):
+                assert np.array_equal(np.asarray(alt[k][b]), np.asarray(want[k][b]))
+
+
+def test_ref_ragged_counts_pack_as_object_array(pkg, dev, monkeypatch):
+    P, DN = pkg.params, pkg.DetectNet
+    pred = pkg.synthetic.make_reference_head(3, seed=5)
+    pred[1] = 0.0                                      # image 1: nothing survives
+    boxes, scores, classes, index = DN.detect(pred.to(dev))
+    assert boxes.dtype == object and boxes.shape == (3,) and boxes.size == 3
+    assert np.asarray(boxes[1]).shape == (0, 4)

@@ -1,0 +1,176 @@
+"""CPU tests of the oracle itself: hand-derivable known answers, the reference's own
+encode formula as a round trip, the two independent restatements against each other, the
+committed golden vectors, and NMS properties."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import np_oracle as npo
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ANCHORS_R = np.array(((0.57273, 0.677385), (1.87446, 2.06253), (3.33843, 5.47434),
+                      (7.88282, 3.52778), (9.77052, 9.16828)))
+syn = importlib.import_module("2d_object_detection_amd.synthetic")
+
+
+def rel(a, b):
+    return float((np.abs(a - b) / np.maximum(np.abs(b), 1e-30)).max()) if a.size else 0.0
+
+
+def test_exp_spec_accuracy_and_limits():
+    xs = np.concatenate([np.linspace(-103.9, 88.7, 20001),
+                         np.random.RandomState(0).randn(20000) * 4]).astype(np.float32)
+    got = oracle.exp_spec(xs).astype(np.float64)
+    ref = np.exp(xs.astype(np.float64))
+    ok = (ref > 1.2e-38) & (ref < 3.3e38)
+    ulp = np.abs(got[ok] - ref[ok]) / np.spacing(ref[ok].astype(np.float32)).astype(np.float64)
+    assert ulp.max() < 2.0
+    assert oracle.exp_spec(np.float32(0.0)) == 1.0
+    assert np.isinf(oracle.exp_spec(np.float32(88.73)))
+    assert oracle.exp_spec(np.float32(-104.5)) == 0.0
+    assert oracle.sigmoid(np.float32(0.0)) == 0.5
+    assert oracle.sigmoid(np.float32(-200.0)) == 0.0
+    assert oracle.sigmoid(np.float32(200.0)) == 1.0
+
+
+def test_reference_mode_all_zero_head_known_answer():
+    c, w, o, p = oracle.r_predict_transform(np.zeros((2, 8450), np.float32), 13, 13, 5, 5, ANCHORS_R)
+    rr, cc = np.meshgrid(np.arange(13), np.arange(13), indexing="ij")
+    # channel 0 carries the COLUMN offset, channel 1 the row offset (detect_net.py:155-162)
+    assert np.allclose(c[0, :, :, 2, 0], (cc + 0.5) / 13, rtol=1e-6)
+    assert np.allclose(c[0, :, :, 2, 1], (rr + 0.5) / 13, rtol=1e-6)
+    assert np.allclose(w[0, 3, 4], ANCHORS_R / 13, rtol=1e-6)
+    assert np.all(o == 0.5) and np.allclose(p, 0.2, rtol=1e-6)
+    boxes, scores, classes, index, surv = oracle.r_filter_boxes(c, w, o, p, 0.6, 0.5, 20, 1280, 1920)
+    assert all(len(x) == 0 for x in boxes) and surv.tolist() == [0, 0]
+
+
+def test_reference_mode_encode_decode_round_trip():
+    """create_dataset.py:101-110 encodes (x-j, y-i, log(w/anchor_w), log(h/anchor_h)); feeding
+    logit(offset) and the log sizes through the decode must give the boxes back."""
+    rs = np.random.RandomState(3)
+    H = W = 13
+    pred = np.zeros((1, H, W, 5, 10), np.float32)
+    truth = []
+    for _ in range(40):
+        i, j, a = rs.randint(H), rs.randint(W), rs.randint(5)
+        fx, fy = rs.uniform(0.05, 0.95, 2)
+        bw, bh = rs.uniform(0.3, 9.0, 2)
+        pred[0, i, j, a, 0] = np.log(fx / (1 - fx))
+        pred[0, i, j, a, 1] = np.log(fy / (1 - fy))
+        pred[0, i, j, a, 2] = np.log(bw / ANCHORS_R[a, 0])
+        pred[0, i, j, a, 3] = np.log(bh / ANCHORS_R[a, 1])
+        truth.append((i, j, a, (j + fx) / W, (i + fy) / H, bw / W, bh / H))
+    c, w, _, _ = oracle.r_predict_transform(pred.reshape(1, -1), H, W, 5, 5, ANCHORS_R)
+    for i, j, a, cx, cy, bw, bh in truth:
+        assert np.allclose(c[0, i, j, a], (cx, cy), rtol=2e-6)
+        assert np.allclose(w[0, i, j, a], (bw, bh), rtol=2e-6)
+
+
+def test_non_square_grid_index_quirk():
+    """(k mod H, k div H) with k = r*W + c, divided by (H, W): detect_net.py:155-168."""
+    H, W = 3, 5
+    c, _, _, _ = oracle.r_predict_transform(np.zeros((1, H * W * 10), np.float32), H, W, 1, 5,
+                                            ANCHORS_R[:1])
+    for r in range(H):
+        for col in range(W):
+            k = r * W + col
+            assert np.allclose(c[0, r, col, 0], ((0.5 + k % H) / H, (0.5 + k // H) / W), rtol=1e-6)
+    assert np.array_equal(c, npo.r_predict_transform(np.zeros((1, H * W * 10), np.float32),
+                                                     H, W, 1, 5, ANCHORS_R[:1])[0])
+
+
+def test_iou_known_values():
+    assert oracle.tf_iou([0, 0, 2, 1], [1, 0, 3, 1]) == np.float32(1.0) / np.float32(3.0)
+    assert oracle.tf_iou([0, 0, 1, 1], [0, 0, 1, 2]) == 0.5
+    assert oracle.tf_iou([1, 1, 0, 0], [0, 0, 1, 1]) == 1.0          # flipped corners
+    assert oracle.tf_iou([0, 0, 0, 5], [0, 0, 1, 1]) == 0.0          # zero area
+    assert oracle.n_iou([0, 0, 9, 9], [0, 0, 9, 9]) == 1.0
+    assert oracle.n_iou([0, 0, 9, 9], [10, 0, 19, 9]) == 0.0         # touching, +1 form
+    assert oracle.n_iou([0, 0, 9, 9], [5, 0, 14, 9]) == np.float32(50.0) / np.float32(150.0)
+    for a, b in (([0, 0, 9, 9], [5, 3, 14, 11]), ([3, 4, 8, 9], [1, 2, 30, 40])):
+        assert oracle.n_iou(a, b) == npo.n_iou(a, b)
+        assert oracle.tf_iou(a, b) == npo.tf_iou(a, b)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_c_and_numpy_restatements_agree_v3(seed):
+    heads = [h.numpy() for h in syn.make_heads(1, 160, seed=seed, clustered=True, n_objects=6)]
+    rows = np.concatenate([oracle.n_predict_transform(h, 160, a, 5)
+                           for h, a in zip(heads, syn.YOLOV3_ANCHORS)], 1)
+    rows_np = np.concatenate([npo.n_predict_transform(h, 160, a, 5)
+                              for h, a in zip(heads, syn.YOLOV3_ANCHORS)], 1)
+    rows_libm = np.concatenate([oracle.n_predict_transform(h, 160, a, 5, oracle.LIBM)
+                                for h, a in zip(heads, syn.YOLOV3_ANCHORS)], 1)
+    assert rel(rows, rows_np) < 1e-5 and rel(rows, rows_libm) < 1e-5
+    det, surv, _ = oracle.n_write_results(rows, 0.5, 5, 0.4)
+    assert np.array_equal(det, npo.n_write_results(rows, 0.5, 5, 0.4))
+    assert 0 < det.shape[0] <= surv.sum()
+
+
+def test_c_and_numpy_restatements_agree_reference():
+    pred = syn.make_reference_head(2, seed=9).numpy()
+    a = oracle.r_predict_transform(pred, 13, 13, 5, 5, ANCHORS_R)
+    b = npo.r_predict_transform(pred, 13, 13, 5, 5, ANCHORS_R)
+    assert max(rel(x, y) for x, y in zip(a, b)) < 1e-5
+    ra = oracle.r_filter_boxes(*a, 0.6, 0.5, 20, 1280, 1920)
+    rb = npo.r_filter_boxes(*a, 0.6, 0.5, 20, 1280, 1920)
+    for k in range(4):
+        for i in range(2):
+            assert np.array_equal(ra[k][i], rb[k][i])
+    assert np.array_equal(ra[4], rb[4])
+
+
+def test_golden_vectors_reproduce():
+    g = np.load(os.path.join(GOLD, "reference_13x13.npz"))
+    c, w, o, p = oracle.r_predict_transform(g["pred"], 13, 13, 5, 5, ANCHORS_R)
+    assert all(np.array_equal(x, g[k]) for x, k in ((c, "center"), (w, "wh"), (o, "obj"), (p, "cls")))
+    boxes, scores, classes, index, surv = oracle.r_filter_boxes(c, w, o, p, 0.6, 0.5, 20, 1280, 1920)
+    assert np.array_equal(np.concatenate(boxes), g["boxes"])
+    assert np.array_equal(np.concatenate(index), g["index"])
+    assert np.array_equal(np.concatenate(classes), g["classes"]) and np.array_equal(surv, g["surv"])
+    g = np.load(os.path.join(GOLD, "yolov3_96.npz"))
+    rows = np.concatenate([oracle.n_predict_transform(g["head%d" % i], 96, a, 5)
+                           for i, a in enumerate(syn.YOLOV3_ANCHORS)], 1)
+    assert np.array_equal(rows, g["rows"])
+    det, surv, _ = oracle.n_write_results(rows, 0.5, 5, 0.4)
+    assert np.array_equal(det, g["det"]) and np.array_equal(surv, g["surv"])
+    g = np.load(os.path.join(GOLD, "nms_edge_cases.npz"))
+    for name, thr in (("t04", 0.4), ("t13", 1.0 / 3.0), ("t05", 0.5), ("t10", 1.0)):
+        assert np.array_equal(oracle.n_write_results(g["rows"], 0.5, 3, thr)[0], g["det_" + name])
+    for name, thr in (("third", 1.0 / 3.0), ("half", 0.5), ("low", 0.3)):
+        assert np.array_equal(oracle.tf_nms(g["tf_boxes"], g["tf_scores"], 10, thr), g["tf_" + name])
+    # IoU exactly at the threshold separates "> thr" from ">= thr"
+    assert 0 in g["tf_half"].tolist() and 0 not in g["tf_third"].tolist()
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_nms_properties(seed):
+    """Kept boxes are pairwise below the threshold, every dropped box is suppressed by an
+    earlier kept one, and the kept set does not depend on the input order (no score ties)."""
+    rs = np.random.RandomState(seed)
+    K = 200
+    yx = rs.rand(K, 2) * 100
+    hw = rs.rand(K, 2) * 40 + 1
+    boxes = np.concatenate([yx, yx + hw], 1).astype(np.float32)
+    scores = rs.permutation(K).astype(np.float32) / K
+    thr = 0.3
+    sel = oracle.tf_nms(boxes, scores, K, thr)
+    assert np.array_equal(sel, npo.tf_nms(boxes, scores, K, thr))
+    assert np.all(np.diff(scores[sel]) < 0)
+    kept = set(sel.tolist())
+    for a in sel:
+        for b in sel:
+            if a != b:
+                assert not oracle.tf_iou(boxes[a], boxes[b]) > thr
+    for j in range(K):
+        if j not in kept:
+            assert any(scores[a] > scores[j] and oracle.tf_iou(boxes[a], boxes[j]) > thr for a in sel)
+    perm = rs.permutation(K)
+    sel_p = oracle.tf_nms(boxes[perm], scores[perm], K, thr)
+    assert np.array_equal(perm[sel_p], sel)
+    capped = oracle.tf_nms(boxes, scores, 7, thr)
+    assert np.array_equal(capped, sel[:7])
