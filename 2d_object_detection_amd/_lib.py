@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "yp_detect_yolov3_workspace_bytes", "yp_detect_yolov3",
     "yp_detect_reference_workspace_bytes", "yp_detect_reference",
     "yp_rows_workspace_bytes", "yp_write_results", "yp_filter_boxes_reference",
-    "yp_bbox_iou",
+    "yp_bbox_iou", "yp_profile_start", "yp_profile_stop",
 )
 
 
@@ -102,6 +102,11 @@ def load():
                                             vp, vp, vp, vp, vp, sz, vp]
     L.yp_bbox_iou.restype = i32
     L.yp_bbox_iou.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.yp_profile_start.restype = i32
+    L.yp_profile_start.argtypes = [i32]
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.yp_profile_stop.restype = i32
+    L.yp_profile_stop.argtypes = [dp, dp, dp, ctypes.POINTER(ctypes.c_int)]
     _lib = L
     return L
 
@@ -139,6 +144,20 @@ def workspace(nbytes, device):
     ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     assert ws.data_ptr() % 256 == 0
     return ws
+
+
+def profile_start(max_calls):
+    check(load().yp_profile_start(int(max_calls)), "yp_profile_start")
+
+
+def profile_stop():
+    """(front_ms, nms_ms, gather_ms, calls): average per-kernel milliseconds since
+    profile_start, measured with HIP events on the stream the calls were enqueued on."""
+    f, n, g = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    c = ctypes.c_int()
+    check(load().yp_profile_stop(ctypes.byref(f), ctypes.byref(n), ctypes.byref(g), ctypes.byref(c)),
+          "yp_profile_stop")
+    return f.value, n.value, g.value, c.value
 
 
 def make_head(t, grid_h, grid_w, anchors, stride_x=0.0, stride_y=0.0):

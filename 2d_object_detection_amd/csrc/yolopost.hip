@@ -883,6 +883,26 @@ SegArgs make_seg_args(const Workspace &w, const YpParams *p, int spi, int tpi, i
     return s;
 }
 
+// Optional per-kernel timing: when enabled, every detect call records four HIP events
+// (before the front kernel and after each of its three launches) on the call's stream.
+struct ProfileState {
+    bool on = false;
+    int max_calls = 0;
+    int calls = 0;
+    hipEvent_t *ev = nullptr;  // 4 per call
+};
+ProfileState g_prof;
+
+inline void prof_mark(hipStream_t st, int k)
+{
+    if (g_prof.on && g_prof.calls < g_prof.max_calls) (void)hipEventRecord(g_prof.ev[4 * g_prof.calls + k], st);
+}
+
+inline void prof_next()
+{
+    if (g_prof.on && g_prof.calls < g_prof.max_calls) ++g_prof.calls;
+}
+
 // Segment NMS + final gather of the YOLOv3 path (shared by the heads and rows entries).
 int finish_v3(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, float *out_rows,
               long long cap, int32_t *out_count, int32_t *stats, hipStream_t st)
@@ -891,6 +911,7 @@ int finish_v3(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, f
     SegArgs s = make_seg_args(w, p, spi, tpi, ts, 1);
     s.max_out = p->max_out;
     hipLaunchKernelGGL(k_segment_nms<YP_MODE_YOLOV3>, dim3(n_seg), dim3(kSegThreads), 0, st, s);
+    prof_mark(st, 2);
     GatherArgs g = {};
     g.n_seg = n_seg;
     g.C = p->num_classes;
@@ -909,6 +930,8 @@ int finish_v3(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, f
     g.out_count = out_count;
     g.stats = stats;
     hipLaunchKernelGGL(k_gather_rows, dim3(n_seg), dim3(256), 0, st, g);
+    prof_mark(st, 3);
+    prof_next();
     return (int)hipGetLastError();
 }
 
@@ -924,6 +947,9 @@ int finish_ref(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, 
     s.out_counts = out_counts;
     s.surv_counts = surv_counts;
     hipLaunchKernelGGL(k_segment_nms<YP_MODE_REFERENCE>, dim3(p->batch), dim3(kSegThreads), 0, st, s);
+    prof_mark(st, 2);
+    prof_mark(st, 3);
+    prof_next();
     return (int)hipGetLastError();
 }
 
@@ -1023,10 +1049,12 @@ int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params, f
     CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, ha.tpi, ts};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ha.tpi, params->batch), block(64 * amax);
+    prof_mark(st, 0);
     if (params->num_classes == 5)
         hipLaunchKernelGGL(k_front_heads_v3<5>, grid, block, 0, st, ha, cb, params->conf_thr);
     else
         hipLaunchKernelGGL(k_front_heads_v3<0>, grid, block, 0, st, ha, cb, params->conf_thr);
+    prof_mark(st, 1);
     return finish_v3(w, params, (int)spi, ha.tpi, ts, d_out_rows, out_cap, d_out_count, d_stats, st);
 }
 
@@ -1065,8 +1093,10 @@ int yp_write_results(const float *d_rows, int rows_per_image, const YpParams *pa
     carve(d_workspace, slots, tiles, (size_t)params->batch * params->num_classes, &w);
     CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile};
     hipStream_t st = (hipStream_t)stream;
+    prof_mark(st, 0);
     hipLaunchKernelGGL(k_front_rows_v3, dim3(tpi, params->batch), dim3(kRowTile), 0, st, d_rows,
                        rows_per_image, params->num_classes, cb, params->conf_thr);
+    prof_mark(st, 1);
     return finish_v3(w, params, (int)spi, tpi, kRowTile, d_out_rows, out_cap, d_out_count, d_stats,
                      st);
 }
@@ -1105,9 +1135,11 @@ int yp_detect_reference(const YpHead *head, const YpParams *params, float *d_out
     AnchorTable at = {};
     for (int i = 0; i < 2 * head->num_anchors; ++i) at.anc[i] = head->anchors[i];
     hipStream_t st = (hipStream_t)stream;
+    prof_mark(st, 0);
     hipLaunchKernelGGL(k_front_grid_ref, dim3(tpi, params->batch), dim3(kRowTile), 0, st,
                        head->data, head->grid_h, head->grid_w, head->num_anchors,
                        params->num_classes, at, cb, params->conf_thr, params->im_h, params->im_w);
+    prof_mark(st, 1);
     return finish_ref(w, params, (int)spi, tpi, kRowTile, d_out_boxes, d_out_scores, d_out_classes,
                       d_out_index, d_out_counts, d_surv_counts, st);
 }
@@ -1135,11 +1167,56 @@ int yp_filter_boxes_reference(const float *d_center, const float *d_wh, const fl
           (size_t)params->batch, &w);
     CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile};
     hipStream_t st = (hipStream_t)stream;
+    prof_mark(st, 0);
     hipLaunchKernelGGL(k_front_split_ref, dim3(tpi, params->batch), dim3(kRowTile), 0, st, d_center,
                        d_wh, d_obj, d_cls, rows_per_image, params->num_classes, cb,
                        params->conf_thr, params->im_h, params->im_w);
+    prof_mark(st, 1);
     return finish_ref(w, params, (int)spi, tpi, kRowTile, d_out_boxes, d_out_scores, d_out_classes,
                       d_out_index, d_out_counts, d_surv_counts, st);
+}
+
+int yp_profile_start(int max_calls)
+{
+    if (max_calls <= 0 || max_calls > (1 << 16) || g_prof.on) return YP_ERR_ARG;
+    g_prof.ev = new hipEvent_t[4 * (size_t)max_calls];
+    for (int i = 0; i < 4 * max_calls; ++i) {
+        const hipError_t e = hipEventCreate(&g_prof.ev[i]);
+        if (e != hipSuccess) return (int)e;
+    }
+    g_prof.max_calls = max_calls;
+    g_prof.calls = 0;
+    g_prof.on = true;
+    return YP_OK;
+}
+
+int yp_profile_stop(double *front_ms, double *nms_ms, double *gather_ms, int *calls)
+{
+    if (!g_prof.on || !front_ms || !nms_ms || !gather_ms || !calls) return YP_ERR_ARG;
+    g_prof.on = false;
+    double acc[3] = {0.0, 0.0, 0.0};
+    int rc = YP_OK;
+    if (g_prof.calls > 0) {
+        const hipError_t e = hipEventSynchronize(g_prof.ev[4 * (g_prof.calls - 1) + 3]);
+        if (e != hipSuccess) rc = (int)e;
+    }
+    for (int c = 0; c < g_prof.calls && rc == YP_OK; ++c)
+        for (int k = 0; k < 3; ++k) {
+            float ms = 0.f;
+            const hipError_t e = hipEventElapsedTime(&ms, g_prof.ev[4 * c + k], g_prof.ev[4 * c + k + 1]);
+            if (e != hipSuccess) { rc = (int)e; break; }
+            acc[k] += ms;
+        }
+    *calls = g_prof.calls;
+    const double n = g_prof.calls > 0 ? (double)g_prof.calls : 1.0;
+    *front_ms = acc[0] / n;
+    *nms_ms = acc[1] / n;
+    *gather_ms = acc[2] / n;
+    for (int i = 0; i < 4 * g_prof.max_calls; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+    delete[] g_prof.ev;
+    g_prof.ev = nullptr;
+    g_prof.max_calls = g_prof.calls = 0;
+    return rc;
 }
 
 int yp_bbox_iou(const float *d_box1, const float *d_boxes2, int m, int row_stride, float *d_out,

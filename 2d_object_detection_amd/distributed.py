@@ -51,6 +51,44 @@ def all_gather_rows(rows, count=None, group=None):
     return torch.cat([r[:c] for r, c in zip(recv, counts)], dim=0), counts
 
 
+class PaddedRowGather:
+    """All-gather of detection rows with a fixed per-rank capacity: no allocation and no
+    host synchronisation per call, so it can follow the kernels on the stream.
+
+    ``send`` is a (cap + 1, W) buffer: row 0 is a header whose first element carries the
+    rank's row count, rows 1.. are the payload (``rows`` is that view; hand it to the engine
+    as its output so nothing is copied).  ``gather`` enqueues ONE all_gather_into_tensor of
+    the whole buffer; ``unpack`` (host side, after the work completed) strips the padding.
+    Counts are carried as float32, exact below 2**24 rows per rank."""
+
+    def __init__(self, cap_rows, width, device, group=None, dtype=torch.float32):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        if not 0 < cap_rows < (1 << 24):
+            raise ValueError("cap_rows must be in (0, 2**24)")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.cap, self.width = int(cap_rows), int(width)
+        self.send = torch.zeros((self.cap + 1, self.width), dtype=dtype, device=device)
+        self.recv = torch.zeros((self.world * (self.cap + 1), self.width), dtype=dtype, device=device)
+
+    @property
+    def rows(self):
+        return self.send[1:]
+
+    def gather(self, count, async_op=False):
+        """count: one-element tensor (any numeric dtype) on the buffer's device."""
+        self.send[0, 0:1].copy_(count.reshape(1))
+        return dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=async_op)
+
+    def unpack(self):
+        """(rows ordered by rank, true counts).  Rows a rank produced beyond ``cap`` were
+        never sent; compare the counts with ``cap`` to detect that."""
+        r = self.recv.view(self.world, self.cap + 1, self.width)
+        counts = [int(c) for c in r[:, 0, 0].tolist()]
+        return torch.cat([r[k, 1:1 + min(c, self.cap)] for k, c in enumerate(counts)], 0), counts
+
+
 class ShardedYoloV3Post:
     """One rank's share of a global batch: a ``YoloV3Post`` over the rank's slice whose
     image indices are offset to global numbering, plus the final all-gather.  The gathered

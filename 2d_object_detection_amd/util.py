@@ -151,7 +151,7 @@ class YoloV3Post:
 
     def __init__(self, batch, inp_dim, num_classes=5, confidence=0.5, nms_conf=0.4,
                  anchors=YOLOV3_ANCHORS, strides=(32, 16, 8), device=None, out_cap=None,
-                 batch_offset=0):
+                 batch_offset=0, out=None):
         self.device = torch.device(device if device is not None
                                    else "cuda:%d" % torch.cuda.current_device())
         if self.device.type != "cuda":
@@ -172,8 +172,16 @@ class YoloV3Post:
         if nbytes == 0:
             raise _lib.YoloPostError("unsupported head geometry")
         self.workspace = _lib.workspace(nbytes, self.device)
-        self.cap = self.batch * self.rows_per_image if out_cap is None else int(out_cap)
-        self.out = torch.empty((max(self.cap, 1), 8), dtype=torch.float32, device=self.device)
+        if out is not None:
+            # caller-provided output rows (e.g. the payload view of a gather buffer)
+            _lib.require_device(out, "out")
+            if (out.dtype != torch.float32 or out.dim() != 2 or out.shape[1] != 8
+                    or not out.is_contiguous() or out.data_ptr() % 16):
+                raise ValueError("out must be a contiguous 16-byte aligned float32 (cap, 8) tensor")
+            self.cap, self.out = out.shape[0], out
+        else:
+            self.cap = self.batch * self.rows_per_image if out_cap is None else int(out_cap)
+            self.out = torch.empty((max(self.cap, 1), 8), dtype=torch.float32, device=self.device)
         self.count = torch.zeros((1,), dtype=torch.int32, device=self.device)
         self.stats = torch.zeros((3, self.batch, self.num_classes), dtype=torch.int32,
                                  device=self.device)

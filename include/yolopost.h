@@ -165,6 +165,18 @@ int yp_filter_boxes_reference(const float *d_center, const float *d_wh, const fl
 int yp_bbox_iou(const float *d_box1, const float *d_boxes2, int m, int row_stride,
                 float *d_out, void *stream);
 
+/* ---- measurement -------------------------------------------------------------------- */
+
+/* Per-kernel timing for benchmarks (no counterpart in the reference).  Between
+ * yp_profile_start and yp_profile_stop every yp_detect_*, yp_write_results and
+ * yp_filter_boxes_reference call records HIP events around its launches, on the stream the
+ * call uses (at most max_calls calls are recorded).  yp_profile_stop waits for the last
+ * recorded event and returns the average milliseconds of the front (decode + filter +
+ * compaction) kernel, the segment NMS kernel and the final gather kernel.  Not thread-safe;
+ * intended for a single measuring thread. */
+int yp_profile_start(int max_calls);
+int yp_profile_stop(double *front_ms, double *nms_ms, double *gather_ms, int *calls);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,16 @@ def _worker(rank, world, port, q):
         ok = ok and c2 == [0] + [2] * (world - 1) and got2.shape[0] == 2 * (world - 1)
         got3, c3 = d.all_gather_rows(rows, 0)
         ok = ok and got3.shape == (0, 8) and c3 == [0] * world
+        # fixed-capacity gather: no host sync on the sending side, padding stripped on unpack
+        pg = d.PaddedRowGather(6, 8, torch.device("cpu"))
+        pg.rows[:n].copy_(rows[:n])
+        pg.gather(torch.tensor([n], dtype=torch.int32))
+        got4, c4 = pg.unpack()
+        ok = ok and c4 == [r * 3 + 1 for r in range(world)]
+        ok = ok and torch.equal(got4[:, :2], want[: got4.shape[0]]) and got4.shape[0] == sum(min(c, 6) for c in c4)
+        h = pg.gather(torch.tensor([2], dtype=torch.int64), async_op=True)
+        h.wait()
+        ok = ok and pg.unpack()[1] == [2] * world
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
