@@ -9,7 +9,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolopost.so")
+# YOLOPOST_LIB may point at another build of the same library (e.g. the diagnostic build with
+# in-kernel time stamps); it is still the HIP library, never a different backend.
+LIB_PATH = os.environ.get("YOLOPOST_LIB") or os.path.join(_HERE, "libyolopost.so")
 
 YP_MAX_HEADS = 4
 YP_MAX_ANCHORS = 8

@@ -31,9 +31,14 @@ namespace {
 typedef unsigned long long u64;
 
 constexpr int kRowTile = 256;     // rows per tile in the row-mapped front kernels
+constexpr int kFrontGroups = 2;   // 64-cell groups per tile of the YOLOv3 heads front kernel
+constexpr int kFrontCells = 64 * kFrontGroups;
 constexpr int kSegThreads = 512;  // threads per NMS workgroup
 constexpr int kSegWaves = kSegThreads / 64;
 constexpr int kSortCap = 4096;    // largest segment sorted in LDS
+constexpr int kSmallCap = 512;    // segments up to this size use the all-pairs LDS bitmask path
+constexpr int kSmallWords = kSmallCap / 64;
+constexpr int kTileCap = 2048;    // tile-count prefix held in LDS up to this many tiles
 
 // ------------------------------------------------------------------------ device structs
 
@@ -94,7 +99,22 @@ struct SegArgs {
     int *out_index;
     int *out_counts;
     int *surv_counts;
+    unsigned long long *dbg;  // diagnostic builds only (YP_STAMPS): 32 time stamps per segment
 };
+
+// In-kernel time stamps exist only in the separate diagnostic build (-DYP_STAMPS); the
+// shipped library compiles STAMP to nothing.
+#ifdef YP_STAMPS
+#define STAMP(k)                                                                        \
+    do {                                                                                \
+        if (threadIdx.x == 0 && s.dbg) {                                                \
+            s.dbg[(size_t)blockIdx.x * 32 + (k)] = wall_clock64();                      \
+            s.dbg[(size_t)blockIdx.x * 32 + 16 + (k)] = clock64();                      \
+        }                                                                               \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 struct GatherArgs {
     int n_seg, C, spi, batch_offset;
@@ -152,12 +172,16 @@ __device__ __forceinline__ int tile_rank_rows(bool pass, u64 *s_bal, int &total)
     return rank;
 }
 
-// Ordered rank when wave w holds anchor w of 64 consecutive cells (row = cell*A + anchor):
-// rows of earlier cells first (any anchor), then earlier anchors of the same cell.
-__device__ __forceinline__ int tile_rank_cells(bool pass, u64 *s_bal, int &total)
+// Ordered rank inside a heads tile.  The block's waves are (group m, anchor a) pairs:
+// wave = m * n_anchor + a holds anchor a of the 64 cells of group m, and the output row
+// order is cell-major, anchor-minor (row = cell * A + anchor).  So a survivor is preceded
+// by every survivor of earlier groups, by the survivors of earlier cells of its group (any
+// anchor) and by the earlier anchors of its own cell.
+__device__ __forceinline__ int tile_rank_cells(bool pass, u64 *s_bal, int n_anchor, int &total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = blockDim.x >> 6;
+    const int m = wave / n_anchor, a = wave - m * n_anchor;
     const u64 bal = __ballot(pass);
     if (lane == 0) s_bal[wave] = bal;
     __syncthreads();
@@ -165,10 +189,15 @@ __device__ __forceinline__ int tile_rank_cells(bool pass, u64 *s_bal, int &total
     int rank = 0;
     total = 0;
     for (int w = 0; w < nw; ++w) {
-        const u64 m = s_bal[w];
-        rank += __popcll(m & below);
-        if (w < wave) rank += (int)((m >> lane) & 1ull);
-        total += __popcll(m);
+        const u64 mk = s_bal[w];
+        const int c = __popcll(mk);
+        const int wm = w / n_anchor, wa = w - wm * n_anchor;
+        if (wm < m) rank += c;
+        else if (wm == m) {
+            rank += __popcll(mk & below);
+            if (wa < a) rank += (int)((mk >> lane) & 1ull);
+        }
+        total += c;
     }
     return rank;
 }
@@ -183,30 +212,42 @@ __device__ __forceinline__ void store_cand(const CandBuf &cb, size_t slot, const
 }
 
 // ------------------------------------------------------------------ front: YOLOv3 heads
-// Block = 64 cells x A anchors of one head of one image; wave w handles anchor w, so every
-// channel load is 64 consecutive floats of one NCHW plane (256 B per wave instruction).
+// Block = kFrontCells cells x A anchors of one head of one image; wave (m, a) handles
+// anchor a of cell group m, so every channel load is 64 consecutive floats of one NCHW
+// plane (256 B per wave instruction).
+//
+// Phase 1 (all lanes): load the channels, decide the confidence filter.  sigmoid is
+// monotone, so objectness logits outside the guard band [t_lo, t_hi] around logit(conf)
+// are decided by a compare; only logits inside the band evaluate the sigmoid (the host
+// passes an infinite band when conf is too close to 0 or 1 for the band to be safe).
+// Survivors are ranked in anchor order with ballots and park their raw logits in LDS.
+// Phase 2 (dense): thread r decodes the tile's r-th survivor, so the transcendental work is
+// done for survivors only instead of by every wave that contains one.
 template <int CS>
-__global__ void k_front_heads_v3(HeadsArgs ha, CandBuf cb, float conf)
+__global__ void k_front_heads_v3(HeadsArgs ha, CandBuf cb, float conf, float t_lo, float t_hi)
 {
-    __shared__ u64 s_bal[YP_MAX_ANCHORS];
+    __shared__ u64 s_bal[kFrontGroups * YP_MAX_ANCHORS];
+    extern __shared__ float s_stage[];
+    constexpr int kStride = 6 + CS;  // t0..t4, packed (anchor, cell), CS class logits
     const int tile = blockIdx.x, b = blockIdx.y;
     int h = 0;
 #pragma unroll
     for (int i = 1; i < YP_MAX_HEADS; ++i)
         if (i < ha.n_heads && tile >= ha.h[i].tile_begin) h = i;
     const HeadGeom &g = ha.h[h];
-    const int lane = threadIdx.x & 63, a = threadIdx.x >> 6;
+    const int n_anchor = blockDim.x / kFrontCells;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = wave / n_anchor, a = wave - m * n_anchor;
     const int C = CS ? CS : ha.C;
     const int V = 5 + C;
     const int cells = g.gh * g.gw;
-    const int cell = (tile - g.tile_begin) * 64 + lane;
+    const int cell = (tile - g.tile_begin) * kFrontCells + m * 64 + lane;
     const bool active = (a < g.A) && (cell < cells);
 
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f;
     float tc[CS ? CS : 1];
-    const float *p = g.data;
     if (active) {
-        p = g.data + ((size_t)(b * g.A + a) * V) * cells + cell;
+        const float *p = g.data + ((size_t)(b * g.A + a) * V) * cells + cell;
         t4 = p[(size_t)4 * cells];
         t0 = p[0];
         t1 = p[(size_t)1 * cells];
@@ -217,40 +258,53 @@ __global__ void k_front_heads_v3(HeadsArgs ha, CandBuf cb, float conf)
             for (int j = 0; j < (CS ? CS : 1); ++j) tc[j] = p[(size_t)(5 + j) * cells];
         }
     }
-    float obj = 0.f;
-    bool pass = false;
-    if (active) {
-        obj = yp_sigmoid(t4);
+    bool pass = active && (t4 >= t_hi);
+    if (active && !pass && !(t4 <= t_lo)) {
+        const float obj = yp_sigmoid(t4);
         pass = (obj > conf) && (obj != 0.0f);
     }
     int total;
-    const int rank = tile_rank_cells(pass, s_bal, total);
+    const int rank = tile_rank_cells(pass, s_bal, n_anchor, total);
     if (pass) {
-        const int row = cell / g.gw, col = cell - row * g.gw;
-        const float cx = (yp_sigmoid(t0) + (float)col) * g.sx;
-        const float cy = (yp_sigmoid(t1) + (float)row) * g.sy;
-        const float w = (yp_exp(t2) * g.anc[2 * a + 0]) * g.sx;
-        const float hgt = (yp_exp(t3) * g.anc[2 * a + 1]) * g.sy;
+        float *st = s_stage + rank * kStride;
+        st[0] = t0; st[1] = t1; st[2] = t2; st[3] = t3; st[4] = t4;
+        reinterpret_cast<int *>(st)[5] = (a << 24) | cell;
+        if (CS) {
+#pragma unroll
+            for (int j = 0; j < (CS ? CS : 1); ++j) st[6 + j] = tc[j];
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < total; r += blockDim.x) {
+        const float *st = s_stage + r * kStride;
+        const int packed = reinterpret_cast<const int *>(st)[5];
+        const int sa = packed >> 24, scell = packed & 0xffffff;
+        const int row = scell / g.gw, col = scell - row * g.gw;
+        const float obj = yp_sigmoid(st[4]);
+        const float cx = (yp_sigmoid(st[0]) + (float)col) * g.sx;
+        const float cy = (yp_sigmoid(st[1]) + (float)row) * g.sy;
+        const float w = (yp_exp(st[2]) * g.anc[2 * sa + 0]) * g.sx;
+        const float hgt = (yp_exp(st[3]) * g.anc[2 * sa + 1]) * g.sy;
         float best;
         int bi = 0;
         if (CS) {
-            best = yp_sigmoid(tc[0]);
+            best = yp_sigmoid(st[6]);
 #pragma unroll
             for (int j = 1; j < (CS ? CS : 1); ++j) {
-                const float s = yp_sigmoid(tc[j]);
-                if (s > best) { best = s; bi = j; }
+                const float sc = yp_sigmoid(st[6 + j]);
+                if (sc > best) { best = sc; bi = j; }
             }
         } else {
+            const float *p = g.data + ((size_t)(b * g.A + sa) * V) * cells + scell;
             best = yp_sigmoid(p[(size_t)5 * cells]);
             for (int j = 1; j < C; ++j) {
-                const float s = yp_sigmoid(p[(size_t)(5 + j) * cells]);
-                if (s > best) { best = s; bi = j; }
+                const float sc = yp_sigmoid(p[(size_t)(5 + j) * cells]);
+                if (sc > best) { best = sc; bi = j; }
             }
         }
         const float hw = w * 0.5f, hh = hgt * 0.5f;
         YpBox bx = {cx - hw, cy - hh, cx + hw, cy + hh};
-        const size_t slot = ((size_t)b * cb.tpi + tile) * cb.ts + rank;
-        store_cand(cb, slot, bx, obj + 0.0f, best, bi);
+        store_cand(cb, ((size_t)b * cb.tpi + tile) * cb.ts + r, bx, obj + 0.0f, best, bi);
     }
     if (threadIdx.x == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = total;
 }
@@ -369,8 +423,8 @@ __global__ void k_front_rows_v3(const float *rows, int N, int C, CandBuf cb, flo
     if (threadIdx.x == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = total;
 }
 
-// --------------------------------------------------------------------------- bitonic sort
-// Ascending sort of n_pad (power of two) 64-bit keys by the whole workgroup.
+// --------------------------------------------------------------------------------- sorting
+// Ascending bitonic sort of n_pad (power of two) 64-bit keys by the whole workgroup.
 template <class KeyPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr keys, int n_pad)
 {
@@ -392,16 +446,196 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr keys, int n_pad)
     }
 }
 
+// Rank sort of K <= kSmallCap distinct keys: element e counts the keys below it and lands
+// at that position.  `in` is padded with ~0 up to a multiple of 8 keys.  When K is small,
+// S = 2^k threads share one element (each counts a slice of the keys, combined with
+// xor-shuffles) so the whole workgroup works; every lane of a wave reads the same LDS
+// address pair at a time (broadcast reads).  One barrier at the end.
+__device__ __forceinline__ void rank_sort(const u64 *in, u64 *out, int K)
+{
+    const int kp = (K + 7) & ~7;
+    int S = 1;
+    while (S < 8 && K * (S << 1) <= kSegThreads) S <<= 1;
+    const int e = threadIdx.x / S, sub = threadIdx.x & (S - 1);
+    const int len = ((kp / 8 + S - 1) / S) * 8;      // keys per slice, multiple of 8
+    const int j0 = sub * len;
+    const int j1 = (j0 + len) < kp ? (j0 + len) : kp;
+    const u64 mine = e < K ? in[e] : 0ull;
+    const ulonglong2 *in2 = reinterpret_cast<const ulonglong2 *>(in);
+    int rank = 0;
+    for (int j = j0; j < j1; j += 8) {
+        const ulonglong2 a = in2[j >> 1], b = in2[(j >> 1) + 1], c = in2[(j >> 1) + 2],
+                         d = in2[(j >> 1) + 3];
+        rank += (a.x < mine) + (a.y < mine) + (b.x < mine) + (b.y < mine);
+        rank += (c.x < mine) + (c.y < mine) + (d.x < mine) + (d.y < mine);
+    }
+    for (int off = 1; off < S; off <<= 1) rank += __shfl_xor(rank, off, 64);
+    if (e < K && sub == 0) out[rank] = mine;
+    __syncthreads();
+}
+
+__device__ __forceinline__ u64 uniform64(u64 v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ u64 readlane64(u64 v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
 // ------------------------------------------------------------------------------ segment NMS
+// LDS scratch of the chunk loop.
+struct ChunkShared {
+    float4 cbox[64];   // the chunk's 64 sorted rows
+    YpPrep kprep[64];  // kept rows of the chunk, prepared for IoU tests
+    u64 sup[64];       // row l: later rows of the chunk that row l suppresses
+    u64 mask[2];       // [0] alive rows of the chunk, [1] kept rows of the chunk
+};
+
+// Greedy NMS over K sorted rows in chunks of 64.  sbox / removed / sslot are indexed by
+// sorted position and live either in LDS (small segments) or in the global workspace.
+// Returns the number of kept rows; emits each kept row through `emit(m, sorted_pos, box)`.
+template <int MODE, class Emit>
+__device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *removed, int K,
+                                          const YpThr thr, int max_out, ChunkShared &sh,
+                                          unsigned int &pairs, Emit emit)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nkept = 0;
+    for (int r0 = 0; r0 < K && nkept < max_out; r0 += 64) {
+        u64 alive0 = 0ull;  // meaningful in wave 0
+        if (wave == 0) {
+            const int i = r0 + lane;
+            float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool alive = false;
+            if (i < K) {
+                bx = sbox[i];
+                alive = removed[i] == 0;
+            }
+            sh.cbox[lane] = bx;
+            alive0 = __ballot(alive);
+            if (lane == 0) sh.mask[0] = alive0;
+        }
+        __syncthreads();
+        const u64 alive_mask = uniform64(sh.mask[0]);
+        if (alive_mask == 0ull) {
+            __syncthreads();
+            continue;
+        }
+        // 64x64 suppression bitmask tile: wave w builds rows w, w+8, ...; lane = column
+        {
+            const float4 cj = sh.cbox[lane];
+            const YpBox bj = {cj.x, cj.y, cj.z, cj.w};
+            const YpPrep pj = yp_prep<MODE>(bj);
+            const bool col_alive = (alive_mask >> lane) & 1ull;
+            for (int l = wave; l < 64; l += 2 * kSegWaves) {
+                const int l2 = l + kSegWaves;
+                const bool a1 = (alive_mask >> l) & 1ull, a2 = (alive_mask >> l2) & 1ull;
+                u64 m1 = 0ull, m2 = 0ull;
+                if (a1 || a2) {
+                    const float4 c1 = sh.cbox[l], c2 = sh.cbox[l2];
+                    const YpBox b1 = {c1.x, c1.y, c1.z, c1.w}, b2 = {c2.x, c2.y, c2.z, c2.w};
+                    const YpPrep p1 = yp_prep<MODE>(b1), p2 = yp_prep<MODE>(b2);
+                    const bool t1 = a1 && (lane > l) && col_alive;
+                    const bool t2 = a2 && (lane > l2) && col_alive;
+                    const bool s1 = t1 && yp_suppresses<MODE>(p1, pj, thr);
+                    const bool s2 = t2 && yp_suppresses<MODE>(p2, pj, thr);
+                    m1 = __ballot(s1);
+                    m2 = __ballot(s2);
+                    pairs += (t1 ? 1u : 0u) + (t2 ? 1u : 0u);
+                }
+                if (lane == 0) {
+                    sh.sup[l] = m1;
+                    sh.sup[l2] = m2;
+                }
+            }
+        }
+        __syncthreads();
+        // wavefront sweep: lane l holds row l's mask; walk the alive rows in order
+        if (wave == 0) {
+            const u64 mysup = sh.sup[lane];
+            u64 alive = alive_mask, keptm = 0ull;
+            int nk = nkept;
+            while (alive != 0ull && nk < max_out) {
+                const int l = __ffsll((long long)alive) - 1;
+                const u64 bit = 1ull << l;
+                keptm |= bit;
+                ++nk;
+                alive &= ~(readlane64(mysup, l) | bit);
+            }
+            if (lane == 0) sh.mask[1] = keptm;
+            if ((keptm >> lane) & 1ull) {
+                const int pos = __popcll(keptm & lanes_below(lane));
+                const float4 cb4 = sh.cbox[lane];
+                const YpBox bl = {cb4.x, cb4.y, cb4.z, cb4.w};
+                sh.kprep[pos] = yp_prep<MODE>(bl);
+                emit(nkept + pos, r0 + lane, cb4);
+            }
+        }
+        __syncthreads();
+        const int nkc = __popcll(uniform64(sh.mask[1]));
+        nkept += nkc;
+        if (nkept >= max_out) break;
+        // column pass: the later columns are tested against the chunk's kept rows.  When
+        // there are fewer columns than threads, G = 2^k lanes share one column (each takes
+        // every G-th kept row) and combine their verdicts with a ballot.
+        const int ncols = K - (r0 + 64);
+        if (nkc > 0 && ncols > 0) {
+            int G = 1;
+            while (G < 64 && ncols * (G << 1) <= kSegThreads) G <<= 1;
+            const int g = tid & (G - 1);
+            const int cpp = kSegThreads / G;  // columns per pass
+            const u64 gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane & ~(G - 1));
+            for (int j0 = r0 + 64; j0 < K; j0 += cpp) {
+                const int j = j0 + tid / G;
+                bool sup = false;
+                const bool live = (j < K) && removed[j] == 0;
+                if (live) {
+                    const float4 cj = sbox[j];
+                    const YpBox bj = {cj.x, cj.y, cj.z, cj.w};
+                    const YpPrep pj = yp_prep<MODE>(bj);
+                    int q = g;
+                    for (; q + G < nkc && !sup; q += 2 * G) {
+                        const bool s0 = yp_suppresses<MODE>(sh.kprep[q], pj, thr);
+                        const bool s1 = yp_suppresses<MODE>(sh.kprep[q + G], pj, thr);
+                        pairs += 2u;
+                        sup = s0 || s1;
+                    }
+                    if (!sup && q < nkc) {
+                        ++pairs;
+                        sup = yp_suppresses<MODE>(sh.kprep[q], pj, thr);
+                    }
+                }
+                if (G == 1) {
+                    if (sup) removed[j] = 1;
+                } else {
+                    const u64 bal = __ballot(sup);
+                    if (g == 0 && live && (bal & gmask) != 0ull) removed[j] = 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    return nkept;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kSegThreads) void k_segment_nms(SegArgs s)
 {
-    __shared__ u64 s_keys[kSortCap];
-    __shared__ float4 s_cbox[64];
-    __shared__ YpPrep s_kprep[64];
-    __shared__ u64 s_sup[64];
-    __shared__ u64 s_mask[2];  // [0] alive rows of the chunk, [1] kept rows of the chunk
-    __shared__ int s_cnt[4];   // [0] classes below, [1] this class, [2] gather cursor
+    // s_raw: sort keys of segments above kSmallCap (bitonic sort, up to kSortCap keys); for
+    // small segments the pairwise suppression bitmask (kSmallWords x kSmallCap words).
+    // s_small (small segments only): [0, 8(cap+8)) gathered keys, later the sorted slot ids;
+    // [8(cap+8), 16(cap+8)) sorted keys; [16(cap+8), 32(cap+8)) sorted boxes.
+    __shared__ __align__(16) unsigned char s_raw[kSortCap * 8];
+    __shared__ __align__(16) unsigned char s_small[32 * (kSmallCap + 8)];
+    __shared__ int s_tpre[kTileCap];
+    __shared__ ChunkShared s_chunk;
+    __shared__ int s_cnt[4];   // [0] candidates of lower classes, [1] of this class
     __shared__ int s_scan[kSegWaves];
     __shared__ unsigned int s_pairs;
 
@@ -411,40 +645,83 @@ __global__ __launch_bounds__(kSegThreads) void k_segment_nms(SegArgs s)
     const int c = s.per_class ? seg - b * s.C : 0;
     const size_t ibase = (size_t)b * s.spi;
     const int *tcount = s.tile_count + (size_t)b * s.tpi;
+    int *gpre = s.tile_prefix + (size_t)b * s.tpi;
     const int tpi = s.tpi, ts = s.ts;
+    const bool pre_lds = tpi <= kTileCap;
 
     if (tid < 4) s_cnt[tid] = 0;
     if (tid == 0) s_pairs = 0u;
-    __syncthreads();
+    STAMP(0);
 
-    // ---- pass 1: how many candidates of this image have a lower class / this class
-    {
-        int lt = 0, eq = 0;
-        for (int tb = wave * 64; tb < tpi; tb += kSegWaves * 64) {
-            const int mycnt = (tb + lane < tpi) ? tcount[tb + lane] : 0;
-            if (!s.per_class) {
-                eq += mycnt;
-                continue;
+    // ---- exclusive prefix of the image's tile counts (LDS when it fits, else global)
+    int k_img = 0;
+    for (int base = 0; base < tpi; base += kSegThreads) {
+        const int v = (base + tid < tpi) ? tcount[base + tid] : 0;
+        const int incl = wave_inclusive_scan(v, lane);
+        if (lane == 63) s_scan[wave] = incl;
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < kSegWaves; ++w) {
+            if (w < wave) woff += s_scan[w];
+            total += s_scan[w];
+        }
+        if (base + tid < tpi) {
+            const int e = k_img + woff + incl - v;
+            if (pre_lds) s_tpre[base + tid] = e;
+            if (!pre_lds || MODE == YP_MODE_REFERENCE) gpre[base + tid] = e;
+        }
+        k_img += total;
+        __syncthreads();
+    }
+
+    STAMP(1);
+    // ---- gather: thread q takes the image's q-th candidate (binary search of its tile),
+    // keeps it if it belongs to this segment and appends its sort key
+    u64 *keys_in = reinterpret_cast<u64 *>(s_raw);
+    u64 *keys_small = reinterpret_cast<u64 *>(s_small);
+    u64 *gk = s.gkeys + 2 * ibase;  // rebased to the segment's region below
+    auto gather = [&](bool to_lds, u64 *gdst) {
+        int lt = 0;
+        for (int q0 = 0; q0 < k_img; q0 += kSegThreads) {
+            const int q = q0 + tid;
+            bool mine = false, below = false;
+            u64 key = 0ull;
+            if (q < k_img) {
+                int lo = 0, hi = tpi;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    const int pm = pre_lds ? s_tpre[mid] : gpre[mid];
+                    if (pm <= q) lo = mid; else hi = mid;
+                }
+                const int slot = lo * ts + (q - (pre_lds ? s_tpre[lo] : gpre[lo]));
+                const float kf = s.cand_key[ibase + slot];
+                const int cl = s.per_class ? s.cand_cls[ibase + slot] : c;
+                below = cl < c;
+                mine = cl == c;
+                key = ((u64)(~yp_float_order_bits(kf)) << 32) | (u64)(unsigned int)slot;
             }
-            if (__ballot(mycnt > 0) == 0ull) continue;
-            const int lim = (tpi - tb) < 64 ? (tpi - tb) : 64;
-            for (int i = 0; i < lim; ++i) {
-                const int cnt = __shfl(mycnt, i, 64);
-                for (int r = lane; r < cnt; r += 64) {
-                    const int cl = s.cand_cls[ibase + (size_t)(tb + i) * ts + r];
-                    lt += (cl < c) ? 1 : 0;
-                    eq += (cl == c) ? 1 : 0;
+            lt += __popcll(__ballot(below));   // wave-uniform count
+            const u64 m = __ballot(mine);
+            if (m != 0ull) {
+                int basepos = 0;
+                if (lane == 0) basepos = atomicAdd(&s_cnt[1], __popcll(m));
+                basepos = __shfl(basepos, 0, 64);
+                if (mine) {
+                    const int pos = basepos + __popcll(m & lanes_below(lane));
+                    if (to_lds) {
+                        if (pos < kSortCap) keys_in[pos] = key;
+                        if (pos < kSmallCap) keys_small[pos] = key;
+                    } else {
+                        gdst[pos] = key;
+                    }
                 }
             }
         }
-        lt = wave_sum(lt);
-        eq = wave_sum(eq);
-        if (lane == 0) {
-            if (lt) atomicAdd(&s_cnt[0], lt);
-            if (eq) atomicAdd(&s_cnt[1], eq);
-        }
-    }
+        if (lane == 0 && lt) atomicAdd(&s_cnt[0], lt);
+    };
+    gather(true, nullptr);
     __syncthreads();
+    STAMP(2);
     const int K = s_cnt[1];
     const int region = s_cnt[0];
     const size_t reg = ibase + region;
@@ -452,27 +729,6 @@ __global__ __launch_bounds__(kSegThreads) void k_segment_nms(SegArgs s)
         s.seg_cand[seg] = K;
         s.seg_region[seg] = region;
     }
-
-    // reference mode reports positions in the image's compacted survivor list, which needs
-    // the exclusive prefix of the tile counts
-    if (MODE == YP_MODE_REFERENCE) {
-        int carry = 0;
-        for (int base = 0; base < tpi; base += kSegThreads) {
-            const int v = (base + tid < tpi) ? tcount[base + tid] : 0;
-            const int incl = wave_inclusive_scan(v, lane);
-            if (lane == 63) s_scan[wave] = incl;
-            __syncthreads();
-            int woff = 0, total = 0;
-            for (int w = 0; w < kSegWaves; ++w) {
-                if (w < wave) woff += s_scan[w];
-                total += s_scan[w];
-            }
-            if (base + tid < tpi) s.tile_prefix[(size_t)b * tpi + base + tid] = carry + woff + incl - v;
-            carry += total;
-            __syncthreads();
-        }
-    }
-
     if (K == 0) {
         if (tid == 0) {
             s.seg_kept[seg] = 0;
@@ -485,144 +741,154 @@ __global__ __launch_bounds__(kSegThreads) void k_segment_nms(SegArgs s)
         return;
     }
 
-    // ---- pass 2: gather sort keys (key descending, slot ascending)
-    const bool in_lds = K <= kSortCap;
-    u64 *gk = s.gkeys + 2 * reg;
-    int n_pad = 2;
-    while (n_pad < K) n_pad <<= 1;
-    for (int tb = wave * 64; tb < tpi; tb += kSegWaves * 64) {
-        const int mycnt = (tb + lane < tpi) ? tcount[tb + lane] : 0;
-        if (__ballot(mycnt > 0) == 0ull) continue;
-        const int lim = (tpi - tb) < 64 ? (tpi - tb) : 64;
-        for (int i = 0; i < lim; ++i) {
-            const int cnt = __shfl(mycnt, i, 64);
-            for (int r = lane; r < cnt; r += 64) {
-                const int slot = (tb + i) * ts + r;
-                if (s.per_class && s.cand_cls[ibase + slot] != c) continue;
-                const u64 key = ((u64)(~yp_float_order_bits(s.cand_key[ibase + slot])) << 32) |
-                                (u64)(unsigned int)slot;
-                const int pos = atomicAdd(&s_cnt[2], 1);
-                if (in_lds) s_keys[pos] = key;
-                else gk[pos] = key;
-            }
-        }
-    }
-    for (int i = K + tid; i < n_pad; i += kSegThreads) {
-        if (in_lds) s_keys[i] = ~0ull;
-        else gk[i] = ~0ull;
-    }
-    __syncthreads();
-
-    // ---- sort, then lay the segment out in sorted order
-    if (in_lds) bitonic_sort(s_keys, n_pad);
-    else bitonic_sort(gk, n_pad);
-    for (int i = tid; i < K; i += kSegThreads) {
-        const int slot = (int)(unsigned int)((in_lds ? s_keys[i] : gk[i]) & 0xffffffffull);
-        s.sslot[reg + i] = slot;
-        s.sbox[reg + i] = s.cand_box[ibase + slot];
-        s.removed[reg + i] = 0;
-    }
-    __syncthreads();
-
-    // ---- greedy NMS over chunks of 64 sorted rows
     const int max_out = s.max_out > 0 ? s.max_out : 0x7fffffff;
-    const float thr = s.thr;
-    int nkept = 0;
     unsigned int pairs = 0;
-    for (int r0 = 0; r0 < K && nkept < max_out; r0 += 64) {
-        if (wave == 0) {
-            const int i = r0 + lane;
-            const bool valid = i < K;
-            float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-            bool alive = false;
-            if (valid) {
-                bx = s.sbox[reg + i];
-                alive = s.removed[reg + i] == 0;
-            }
-            s_cbox[lane] = bx;
-            const u64 am = __ballot(alive);
-            if (lane == 0) s_mask[0] = am;
-        }
-        __syncthreads();
-        const u64 alive_mask = s_mask[0];
-        if (alive_mask == 0ull) {
-            __syncthreads();
-            continue;
-        }
-        // 64x64 suppression bitmask tile: wave w builds rows w, w+8, ...; lane = column
-        {
-            const float4 cj = s_cbox[lane];
-            const YpBox bj = {cj.x, cj.y, cj.z, cj.w};
-            const YpPrep pj = yp_prep<MODE>(bj);
-            for (int l = wave; l < 64; l += kSegWaves) {
-                u64 m = 0ull;
-                if ((alive_mask >> l) & 1ull) {
-                    const float4 cl = s_cbox[l];
-                    const YpBox bl = {cl.x, cl.y, cl.z, cl.w};
-                    const YpPrep pl = yp_prep<MODE>(bl);
-                    const bool sup = (lane > l) && ((alive_mask >> lane) & 1ull) &&
-                                     yp_suppresses<MODE>(pl, pj, thr);
-                    m = __ballot(sup);
-                    pairs += (lane > l) && ((alive_mask >> lane) & 1ull) ? 1u : 0u;
-                }
-                if (lane == 0) s_sup[l] = m;
-            }
-        }
-        __syncthreads();
-        // wavefront sweep of the tile + emission of the kept rows
-        if (wave == 0) {
-            u64 alive = alive_mask, keptm = 0ull;
-            int nk = nkept;
-            for (int l = 0; l < 64; ++l) {
-                if (((alive >> l) & 1ull) && nk < max_out) {
-                    keptm |= 1ull << l;
-                    ++nk;
-                    alive &= ~s_sup[l];
-                }
-            }
-            if (lane == 0) s_mask[1] = keptm;
-            if ((keptm >> lane) & 1ull) {
-                const int pos = __popcll(keptm & lanes_below(lane));
-                const float4 cb4 = s_cbox[lane];
-                const YpBox bl = {cb4.x, cb4.y, cb4.z, cb4.w};
-                s_kprep[pos] = yp_prep<MODE>(bl);
-                const int slot = s.sslot[reg + r0 + lane];
-                const int m = nkept + pos;
-                if (MODE == YP_MODE_REFERENCE) {
-                    const size_t q = (size_t)b * s.max_out + m;
-                    reinterpret_cast<float4 *>(s.out_boxes)[q] = cb4;
-                    s.out_scores[q] = s.cand_key[ibase + slot];
-                    s.out_classes[q] = s.cand_cls[ibase + slot];
-                    const int tile = slot / ts;
-                    s.out_index[q] = s.tile_prefix[(size_t)b * tpi + tile] + (slot - tile * ts);
-                } else {
-                    s.kept_slot[reg + m] = slot;
-                }
-            }
-        }
-        __syncthreads();
-        const int nkc = __popcll(s_mask[1]);
-        nkept += nkc;
-        if (nkept >= max_out) break;
-        // column pass: each thread tests the later columns it owns against the kept rows
-        if (nkc > 0) {
-            for (int j = r0 + 64 + tid; j < K; j += kSegThreads) {
-                if (s.removed[reg + j]) continue;
-                const float4 cj = s.sbox[reg + j];
-                const YpBox bj = {cj.x, cj.y, cj.z, cj.w};
-                const YpPrep pj = yp_prep<MODE>(bj);
-                for (int q = 0; q < nkc; ++q) {
-                    ++pairs;
-                    if (yp_suppresses<MODE>(s_kprep[q], pj, thr)) {
-                        s.removed[reg + j] = 1;
-                        break;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
+    int nkept = 0;
+    const int *sslot_final;  // sorted position -> slot id, readable after the NMS loop
 
+    auto emit_kept = [&](const int *sslot, int m, int sorted_pos, const float4 &bx) {
+        const int slot = sslot[sorted_pos];
+        if (MODE == YP_MODE_REFERENCE) {
+            const size_t q = (size_t)b * s.max_out + m;
+            reinterpret_cast<float4 *>(s.out_boxes)[q] = bx;
+            s.out_scores[q] = s.cand_key[ibase + slot];
+            s.out_classes[q] = s.cand_cls[ibase + slot];
+            const int tile = slot / ts;
+            s.out_index[q] = gpre[tile] + (slot - tile * ts);
+        } else {
+            s.kept_slot[reg + m] = slot;
+        }
+    };
+
+    if (K <= kSmallCap) {
+        // ---- small segment: rank sort, then the full pairwise suppression bitmask in LDS
+        // (word-major: cmask[w * kSmallCap + j] holds, for column j, the rows 64w..64w+63
+        // that precede j in sorted order and suppress it) and a sweep by wave 0 that needs
+        // no barriers and no IoU arithmetic.
+        u64 *cmask = reinterpret_cast<u64 *>(s_raw);
+        u64 *keys_out = reinterpret_cast<u64 *>(s_small + 8 * (kSmallCap + 8));
+        float4 *lbox = reinterpret_cast<float4 *>(s_small + 16 * (kSmallCap + 8));
+        int *lslot = reinterpret_cast<int *>(s_small);
+        for (int i = K + tid; i < ((K + 7) & ~7); i += kSegThreads) keys_small[i] = ~0ull;
+        __syncthreads();
+        rank_sort(keys_small, keys_out, K);
+        STAMP(3);
+        for (int i = tid; i < K; i += kSegThreads) {
+            const int slot = (int)(unsigned int)(keys_out[i] & 0xffffffffull);
+            lslot[i] = slot;
+            lbox[i] = s.cand_box[ibase + slot];
+        }
+        __syncthreads();
+        STAMP(4);
+        const int nwords = (K + 63) >> 6;
+        const YpThr thr = yp_make_thr(s.thr);
+        // all-pairs tile: lanes hold the 64 rows of word w; each wave walks the columns
+        // j >= 64w it owns, four at a time (independent tests, so their latencies overlap)
+        for (int w = 0; w < nwords; ++w) {
+            const int i = (w << 6) + lane;
+            const float4 ci = lbox[i < K ? i : 0];
+            const YpBox bi = {ci.x, ci.y, ci.z, ci.w};
+            const YpPrep pi = yp_prep<MODE>(bi);
+            for (int j0 = (w << 6) + wave; j0 < K; j0 += 4 * kSegWaves) {
+                int verdict[4];
+                YpPrep pj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u * kSegWaves;
+                    const float4 cj = lbox[j < K ? j : 0];
+                    const YpBox bj = {cj.x, cj.y, cj.z, cj.w};
+                    pj[u] = yp_prep<MODE>(bj);
+                    const bool test = (i < j) && (j < K);
+                    const int v = yp_suppress_pretest<MODE>(pi, pj[u], thr);
+                    verdict[u] = test ? v : 0;
+                    pairs += test ? 1u : 0u;
+                }
+                bool sup[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    sup[u] = verdict[u] == 1;
+                    if (verdict[u] == 2) sup[u] = yp_suppresses_exact<MODE>(pi, pj[u], thr.thr);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u * kSegWaves;
+                    const u64 word = __ballot(sup[u]);
+                    if (lane == 0 && j < K) cmask[w * kSmallCap + j] = word;
+                }
+            }
+        }
+        __syncthreads();
+        STAMP(7);
+        if (wave == 0) {
+            u64 keptw[kSmallWords];
+#pragma unroll
+            for (int w = 0; w < kSmallWords; ++w) keptw[w] = 0ull;
+#pragma unroll
+            for (int cw = 0; cw < kSmallWords; ++cw) {
+                if (cw < nwords && nkept < max_out) {
+                    const int j = (cw << 6) + lane;
+                    bool alive = j < K;
+#pragma unroll
+                    for (int w = 0; w < cw; ++w)
+                        alive = alive && (cmask[w * kSmallCap + (j < K ? j : 0)] & keptw[w]) == 0ull;
+                    const u64 mycol = (j < K) ? cmask[cw * kSmallCap + j] : 0ull;
+                    // greedy keep set of the chunk as the fixed point of
+                    // keep[i] = alive[i] && no kept earlier row of the chunk suppresses i
+                    u64 keep = __ballot(alive);
+                    for (int it = 0; it < 66; ++it) {
+                        const u64 nk = __ballot(alive && (mycol & keep) == 0ull);
+                        if (nk == keep) break;
+                        keep = nk;
+                    }
+                    const int room = max_out - nkept;
+                    if (__popcll(keep) > room)
+                        keep = __ballot(((keep >> lane) & 1ull) && __popcll(keep & lanes_below(lane)) < room);
+                    keptw[cw] = keep;
+                    if ((keep >> lane) & 1ull)
+                        emit_kept(lslot, nkept + __popcll(keep & lanes_below(lane)), j, lbox[j]);
+                    nkept += __popcll(keep);
+                }
+            }
+        }
+        sslot_final = lslot;
+    } else {
+        // ---- large segment: bitonic sort (LDS up to kSortCap keys, else global), sorted
+        // boxes / flags / slots in the global workspace region of the segment
+        int n_pad = 2;
+        while (n_pad < K) n_pad <<= 1;
+        const bool in_lds = K <= kSortCap;
+        u64 *gdst = gk + 2 * (size_t)region;
+        if (!in_lds) {
+            __syncthreads();
+            if (tid == 0) s_cnt[1] = 0;
+            if (tid == 1) s_cnt[0] = 0;
+            __syncthreads();
+            gather(false, gdst);
+        }
+        for (int i = K + tid; i < n_pad; i += kSegThreads) {
+            if (in_lds) keys_in[i] = ~0ull;
+            else gdst[i] = ~0ull;
+        }
+        __syncthreads();
+        if (in_lds) bitonic_sort(keys_in, n_pad);
+        else bitonic_sort(gdst, n_pad);
+        float4 *gbox = s.sbox + reg;
+        int *gslot = s.sslot + reg;
+        unsigned char *grem = s.removed + reg;
+        for (int i = tid; i < K; i += kSegThreads) {
+            const int slot = (int)(unsigned int)((in_lds ? keys_in[i] : gdst[i]) & 0xffffffffull);
+            gslot[i] = slot;
+            gbox[i] = s.cand_box[ibase + slot];
+            grem[i] = 0;
+        }
+        __syncthreads();
+        sslot_final = gslot;
+        nkept = nms_chunks<MODE>(gbox, grem, K, yp_make_thr(s.thr), max_out, s_chunk, pairs,
+                                 [&](int m, int sp, const float4 &bx) { emit_kept(gslot, m, sp, bx); });
+    }
+    (void)sslot_final;
+
+    STAMP(5);
     pairs = (unsigned int)wave_sum((int)pairs);
     if (lane == 0 && pairs) atomicAdd(&s_pairs, pairs);
     __syncthreads();
@@ -634,6 +900,7 @@ __global__ __launch_bounds__(kSegThreads) void k_segment_nms(SegArgs s)
             s.surv_counts[b] = K;
         }
     }
+    STAMP(6);
 }
 
 // --------------------------------------------------------------------- final row gather
@@ -747,6 +1014,7 @@ __global__ void k_bbox_iou(const float *box1, const float *boxes2, int m, int ro
 // ------------------------------------------------------------------------------ host side
 
 constexpr size_t kAlign = 256;
+unsigned long long *g_dbg = nullptr;  // set only through yp_debug_set_stamps (diagnostic build)
 
 struct Workspace {
     float4 *cand_box;
@@ -807,8 +1075,10 @@ bool params_ok(const YpParams *p, int mode)
     return true;
 }
 
-// Geometry of a set of YOLOv3 heads: tiles of 64 cells, slots per tile = 64 * max anchors.
-int heads_geometry(const YpHead *heads, int n_heads, int C, HeadsArgs *ha, int *amax_out)
+// Geometry of a set of YOLOv3 heads: tiles of cells_per_tile cells, slots per tile =
+// cells_per_tile * max anchors.
+int heads_geometry(const YpHead *heads, int n_heads, int C, int cells_per_tile, HeadsArgs *ha,
+                   int *amax_out)
 {
     if (!heads || n_heads < 1 || n_heads > YP_MAX_HEADS) return YP_ERR_ARG;
     int amax = 0;
@@ -828,7 +1098,7 @@ int heads_geometry(const YpHead *heads, int n_heads, int C, HeadsArgs *ha, int *
         g.tile_begin = (int)tiles;
         g.row_begin = (int)rows;
         for (int k = 0; k < 2 * YP_MAX_ANCHORS; ++k) g.anc[k] = h.anchors[k];
-        tiles += ((long long)h.grid_h * h.grid_w + 63) / 64;
+        tiles += ((long long)h.grid_h * h.grid_w + cells_per_tile - 1) / cells_per_tile;
         rows += (long long)h.grid_h * h.grid_w * h.num_anchors;
         amax = h.num_anchors > amax ? h.num_anchors : amax;
     }
@@ -840,6 +1110,23 @@ int heads_geometry(const YpHead *heads, int n_heads, int C, HeadsArgs *ha, int *
     ha->N = (int)rows;
     *amax_out = amax;
     return YP_OK;
+}
+
+// Guard band around logit(conf) outside which the confidence filter sigmoid(t) > conf is
+// decided by comparing t: sigmoid(t_hi) exceeds conf, and sigmoid(t_lo) falls short of it, by
+// orders of magnitude more than the error of the computed sigmoid.  For conf outside
+// [1e-6, 0.99] the band is infinite, i.e. every objectness goes through the sigmoid.
+void logit_band(float conf, float *t_lo, float *t_hi)
+{
+    *t_lo = -__builtin_inff();
+    *t_hi = __builtin_inff();
+    if (conf >= 1e-6f && conf <= 0.99f) {
+        const double c = (double)conf;
+        const double l = __builtin_log(c / (1.0 - c));
+        const double d = 1e-3 * (__builtin_fabs(l) > 1.0 ? __builtin_fabs(l) : 1.0);
+        *t_lo = (float)(l - d);
+        *t_hi = (float)(l + d);
+    }
 }
 
 bool slots_fit(long long batch, long long spi)
@@ -880,6 +1167,7 @@ SegArgs make_seg_args(const Workspace &w, const YpParams *p, int spi, int tpi, i
     s.seg_cand = w.seg_cand;
     s.seg_region = w.seg_region;
     s.seg_pairs = w.seg_pairs;
+    s.dbg = g_dbg;
     return s;
 }
 
@@ -998,7 +1286,7 @@ int yp_predict_transform_yolov3(const YpHead *heads, int n_heads, int batch, int
         return YP_ERR_ARG;
     HeadsArgs ha;
     int amax = 0;
-    const int rc = heads_geometry(heads, n_heads, num_classes, &ha, &amax);
+    const int rc = heads_geometry(heads, n_heads, num_classes, 64, &ha, &amax);
     if (rc != YP_OK) return rc;
     const size_t lds = (size_t)64 * amax * (5 + num_classes) * sizeof(float);
     if (lds > 64 * 1024) return YP_ERR_UNSUPPORTED;
@@ -1019,8 +1307,8 @@ size_t yp_detect_yolov3_workspace_bytes(const YpHead *heads, int n_heads, int ba
         tmp[i] = heads[i];
         if (!tmp[i].data) tmp[i].data = &dummy;  // sizing does not need the data pointers
     }
-    if (heads_geometry(tmp, n_heads, num_classes, &ha, &amax) != YP_OK) return 0;
-    const long long spi = (long long)ha.tpi * 64 * amax;
+    if (heads_geometry(tmp, n_heads, num_classes, kFrontCells, &ha, &amax) != YP_OK) return 0;
+    const long long spi = (long long)ha.tpi * kFrontCells * amax;
     if (!slots_fit(batch, spi)) return 0;
     return carve(nullptr, (size_t)batch * spi, (size_t)batch * ha.tpi,
                  (size_t)batch * num_classes, nullptr);
@@ -1035,9 +1323,9 @@ int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params, f
     if ((reinterpret_cast<uintptr_t>(d_out_rows) & 15) != 0) return YP_ERR_ARG;
     HeadsArgs ha;
     int amax = 0;
-    const int rc = heads_geometry(heads, n_heads, params->num_classes, &ha, &amax);
+    const int rc = heads_geometry(heads, n_heads, params->num_classes, kFrontCells, &ha, &amax);
     if (rc != YP_OK) return rc;
-    const int ts = 64 * amax;
+    const int ts = kFrontCells * amax;
     const long long spi = (long long)ha.tpi * ts;
     if (!slots_fit(params->batch, spi)) return YP_ERR_UNSUPPORTED;
     const size_t slots = (size_t)params->batch * spi, tiles = (size_t)params->batch * ha.tpi;
@@ -1048,12 +1336,16 @@ int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params, f
     carve(d_workspace, slots, tiles, n_seg, &w);
     CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, ha.tpi, ts};
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(ha.tpi, params->batch), block(64 * amax);
+    const dim3 grid(ha.tpi, params->batch), block(kFrontCells * amax);
+    float t_lo, t_hi;
+    logit_band(params->conf_thr, &t_lo, &t_hi);
     prof_mark(st, 0);
     if (params->num_classes == 5)
-        hipLaunchKernelGGL(k_front_heads_v3<5>, grid, block, 0, st, ha, cb, params->conf_thr);
+        hipLaunchKernelGGL(k_front_heads_v3<5>, grid, block, (size_t)ts * (6 + 5) * sizeof(float), st,
+                           ha, cb, params->conf_thr, t_lo, t_hi);
     else
-        hipLaunchKernelGGL(k_front_heads_v3<0>, grid, block, 0, st, ha, cb, params->conf_thr);
+        hipLaunchKernelGGL(k_front_heads_v3<0>, grid, block, (size_t)ts * 6 * sizeof(float), st, ha,
+                           cb, params->conf_thr, t_lo, t_hi);
     prof_mark(st, 1);
     return finish_v3(w, params, (int)spi, ha.tpi, ts, d_out_rows, out_cap, d_out_count, d_stats, st);
 }
@@ -1175,6 +1467,15 @@ int yp_filter_boxes_reference(const float *d_center, const float *d_wh, const fl
     return finish_ref(w, params, (int)spi, tpi, kRowTile, d_out_boxes, d_out_scores, d_out_classes,
                       d_out_index, d_out_counts, d_surv_counts, st);
 }
+
+#ifdef YP_STAMPS
+/* diagnostic build only: device buffer of 32 u64 stamps per NMS segment (or null) */
+int yp_debug_set_stamps(void *d_buf)
+{
+    g_dbg = static_cast<unsigned long long *>(d_buf);
+    return YP_OK;
+}
+#endif
 
 int yp_profile_start(int max_calls)
 {

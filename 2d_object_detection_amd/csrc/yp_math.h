@@ -120,10 +120,65 @@ YP_HD YpPrep yp_prep(const YpBox &q)
 }
 
 template <int MODE>
-YP_HD bool yp_suppresses(const YpPrep &p, const YpPrep &q, float thr)
+YP_HD bool yp_suppresses_exact(const YpPrep &p, const YpPrep &q, float thr)
 {
     if (MODE == 0) return !(yp_iou_v3(p, q) < thr);
     return yp_iou_tf(p, q) > thr;
+}
+
+// Threshold with guard bands for the division-free test below.
+struct YpThr {
+    float thr, lo, hi;
+    bool fast;
+};
+
+YP_HD YpThr yp_make_thr(float thr)
+{
+    YpThr t;
+    t.thr = thr;
+    t.lo = thr * 0.99999904632568359375f;   // thr * (1 - 2^-20)
+    t.hi = thr * 1.00000095367431640625f;   // thr * (1 + 2^-20)
+    t.fast = thr > 1e-30f && thr < 1e30f;
+    return t;
+}
+
+// Division-free pre-test, branch-free so that several independent tests overlap in the
+// pipeline.  Returns 0 (does not suppress), 1 (suppresses) or 2 (undecided: the caller
+// must run yp_suppresses_exact).  With r = inter/union (real), inter < fl(lo*union) implies
+// r < thr*(1 - 2^-21), hence fl(r) < thr by monotonicity of rounding; inter > fl(hi*union)
+// implies fl(r) > thr.  Undecided are only quotients within ~2^-20 of the threshold,
+// non-finite or non-positive unions, and thresholds outside (1e-30, 1e30); so the final
+// verdict equals the divide-and-compare one bit for bit.
+template <int MODE>
+YP_HD int yp_suppress_pretest(const YpPrep &p, const YpPrep &q, const YpThr &t)
+{
+    const float i0 = p.lo0 > q.lo0 ? p.lo0 : q.lo0;
+    const float i1 = p.lo1 > q.lo1 ? p.lo1 : q.lo1;
+    const float j0 = p.hi0 < q.hi0 ? p.hi0 : q.hi0;
+    const float j1 = p.hi1 < q.hi1 ? p.hi1 : q.hi1;
+    float d0 = MODE == 0 ? (j0 - i0 + 1.0f) : (j0 - i0);
+    float d1 = MODE == 0 ? (j1 - i1 + 1.0f) : (j1 - i1);
+    d0 = (d0 > 0.0f) ? d0 : 0.0f;
+    d1 = (d1 > 0.0f) ? d1 : 0.0f;
+    const float inter = d0 * d1;
+    const float uni = p.area + q.area - inter;
+    const bool yes = inter > t.hi * uni;
+    const bool no = inter < t.lo * uni;
+    const bool decided = t.fast & (uni > 1e-30f) & (uni < 1e30f) & (yes | no);
+    int v = decided ? (yes ? 1 : 0) : 2;
+    if (MODE != 0) {
+        const bool degenerate = (p.area <= 0.0f) | (q.area <= 0.0f);
+        v = degenerate ? ((0.0f > t.thr) ? 1 : 0) : v;
+    }
+    return v;
+}
+
+template <int MODE>
+YP_HD bool yp_suppresses(const YpPrep &p, const YpPrep &q, const YpThr &t)
+{
+    const int v = yp_suppress_pretest<MODE>(p, q, t);
+    if (v == 2) return yp_suppresses_exact<MODE>(p, q, t.thr);
+    return v == 1;
 }
 
 // Order-preserving map float -> uint32 (unsigned compare == float compare, NaN excluded).

@@ -22,6 +22,13 @@ float hm_iou_tf(const float* a, const float* b) {
   YpBox p = {a[0], a[1], a[2], a[3]}, q = {b[0], b[1], b[2], b[3]};
   return yp_iou_tf(yp_prep_tf(p), yp_prep_tf(q)); }
 unsigned hm_order(float f) { return yp_float_order_bits(f); }
+int hm_sup(int mode, int fast, const float* a, const float* b, float thr) {
+  YpBox p = {a[0], a[1], a[2], a[3]}, q = {b[0], b[1], b[2], b[3]};
+  if (mode == 0) return fast ? yp_suppresses<0>(yp_prep<0>(p), yp_prep<0>(q), yp_make_thr(thr))
+                             : yp_suppresses_exact<0>(yp_prep<0>(p), yp_prep<0>(q), thr);
+  return fast ? yp_suppresses<1>(yp_prep<1>(p), yp_prep<1>(q), yp_make_thr(thr))
+              : yp_suppresses_exact<1>(yp_prep<1>(p), yp_prep<1>(q), thr);
+}
 }
 '''
 
@@ -39,6 +46,8 @@ def hm(tmp_path_factory):
     L.hm_iou_tf.restype = ctypes.c_float
     L.hm_order.restype = ctypes.c_uint
     L.hm_order.argtypes = [ctypes.c_float]
+    L.hm_sup.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                         ctypes.POINTER(ctypes.c_float), ctypes.c_float]
     return L
 
 
@@ -74,3 +83,35 @@ def test_float_order_bits_is_monotone(hm):
     keys = np.array([hm.hm_order(float(x)) for x in xs], np.uint64)
     assert np.all(np.diff(keys.astype(np.int64)) >= 0)
     assert hm.hm_order(0.0) == hm.hm_order(-0.0)
+
+
+def test_division_free_suppression_test_equals_the_exact_one(hm):
+    """The guarded multiply-compare must give the verdict of the divide-and-compare for
+    every pair, including quotients exactly at, one ulp below and one ulp above the
+    threshold, zero / negative / huge thresholds and degenerate boxes."""
+    rs = np.random.RandomState(5)
+    n_checked = 0
+    for trial in range(3000):
+        a = (rs.rand(4) * 60).astype(np.float32)
+        b = (rs.rand(4) * 60).astype(np.float32)
+        kind = trial % 6
+        if kind < 4:                      # well-formed, overlapping more often than not
+            a[2:] = a[:2] + rs.rand(2).astype(np.float32) * 40 + 1
+            b[:2] = a[:2] + (rs.rand(2).astype(np.float32) - 0.5) * 20
+            b[2:] = b[:2] + rs.rand(2).astype(np.float32) * 40 + 1
+        elif kind == 4:
+            b = a.copy()                  # identical boxes
+        for mode in (0, 1):
+            iou = np.float32(oracle.n_iou(a, b) if mode == 0 else oracle.tf_iou(a, b))
+            thrs = [0.4, 0.5, 0.0, -1.0, 1.0, 1e-35, 1e35, float(rs.rand())]
+            if np.isfinite(iou):
+                thrs += [float(iou), float(np.nextafter(iou, np.float32(2))),
+                         float(np.nextafter(iou, np.float32(-2)))]
+            for thr in thrs:
+                thr = float(np.float32(thr))
+                fast = hm.hm_sup(mode, 1, _p(a), _p(b), thr)
+                exact = hm.hm_sup(mode, 0, _p(a), _p(b), thr)
+                want = (not (iou < np.float32(thr))) if mode == 0 else bool(iou > np.float32(thr))
+                assert fast == exact == int(want), (mode, a, b, thr, iou)
+                n_checked += 1
+    assert n_checked > 50000

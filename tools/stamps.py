@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Diagnostic: where the segment-NMS workgroups spend their time (in-kernel stamps).
+
+Build the diagnostic library first (make -C 2d_object_detection_amd/csrc stamps) and run
+    YOLOPOST_LIB=2d_object_detection_amd/libyolopost_stamps.so python tools/stamps.py
+Stamps are 100 MHz wall-clock ticks taken by thread 0 of every workgroup; the shipped
+library contains none of this."""
+import ctypes
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("2d_object_detection_amd")
+syn, util, _lib = pkg.synthetic, pkg.util, pkg._lib
+
+B, inp = int(os.environ.get("B", 64)), int(os.environ.get("INP", 416))
+dev = torch.device("cuda:0")
+heads = [h.to(dev) for h in syn.make_heads(B, inp, 5, seed=1)]
+eng = util.YoloV3Post(B, inp, 5, 0.5, 0.4, device=dev)
+nseg = B * 5
+dbg = torch.zeros((nseg, 32), dtype=torch.int64, device=dev)
+L = _lib.load()
+L.yp_debug_set_stamps.argtypes = [ctypes.c_void_p]
+for _ in range(5):
+    eng.run(heads)
+L.yp_debug_set_stamps(dbg.data_ptr())
+eng.run(heads)
+torch.cuda.synchronize()
+L.yp_debug_set_stamps(None)
+t = dbg.cpu().numpy().astype(np.float64) * 10.0 / 1000.0   # ticks of 10 ns -> us
+names = ["prefix", "gather", "sort", "boxes", "nms(all)", "final"]
+t0 = t[:, 0].min()
+print("segments %d; first start %.2f us, last start %.2f us, last end %.2f us (relative)"
+      % (nseg, 0.0, (t[:, 0] - t0).max(), (t[:, 6] - t0).max()))
+for k, n in enumerate(names):
+    d = t[:, k + 1] - t[:, k]
+    print("%-8s mean %.2f us  max %.2f us" % (n, d.mean(), d.max()))
+print("block total mean %.2f us max %.2f us" % ((t[:, 6] - t[:, 0]).mean(), (t[:, 6] - t[:, 0]).max()))
+if t[:, 7].max() > 0:
+    print("small path: pair matrix mean %.2f us, sweep mean %.2f us"
+          % ((t[:, 7] - t[:, 4]).mean(), (t[:, 5] - t[:, 7]).mean()))
+
+raw = dbg.cpu().numpy().astype(np.float64)
+dc = raw[:, 16 + 5] - raw[:, 16 + 4]
+dt = (raw[:, 5] - raw[:, 4]) * 10e-9
+print("shader clock during the NMS phase: %.0f MHz (cycles / wall time, median over segments)"
+      % float(np.median(dc / dt) / 1e6))
