@@ -35,9 +35,13 @@ constexpr int kFrontGroups = 2;   // 64-cell groups per tile of the YOLOv3 heads
 constexpr int kFrontCells = 64 * kFrontGroups;
 constexpr int kSegThreads = 512;  // threads per NMS workgroup
 constexpr int kSegWaves = kSegThreads / 64;
-constexpr int kSortCap = 4096;    // largest segment sorted in LDS
+constexpr int kSortCap = 2048;    // largest segment sorted in LDS
 constexpr int kSmallCap = 512;    // segments up to this size use the all-pairs LDS bitmask path
 constexpr int kSmallWords = kSmallCap / 64;
+// words of the triangular pairwise bitmask of a kSmallCap segment: sum_w (cap - 64 w)
+constexpr int kMaskWords = kSmallWords * kSmallCap - 32 * kSmallWords * (kSmallWords - 1);
+constexpr int kRawBytes = (kSortCap * 8 > kMaskWords * 8) ? kSortCap * 8 : kMaskWords * 8;
+constexpr int kSmallBytes = 32 * (kSmallCap + 8);
 constexpr int kTileCap = 2048;    // tile-count prefix held in LDS up to this many tiles
 
 // ------------------------------------------------------------------------ device structs
@@ -153,6 +157,22 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
 
 __device__ __forceinline__ u64 lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
+// Single-instruction max/min.  For non-NaN operands they equal (a > b ? a : b) and
+// (a < b ? a : b); written as asm because the compiler pairs every such select with a
+// compare, and canonicalises the operands of the fmaxf/fminf/fmed3 builtins first.
+__device__ __forceinline__ float vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Ordered rank of a surviving thread inside a tile whose threads are in row order
 // (thread t <-> row t of the tile): ballot per wave, popcount prefix over waves.
 __device__ __forceinline__ int tile_rank_rows(bool pass, u64 *s_bal, int &total)
@@ -177,27 +197,28 @@ __device__ __forceinline__ int tile_rank_rows(bool pass, u64 *s_bal, int &total)
 // order is cell-major, anchor-minor (row = cell * A + anchor).  So a survivor is preceded
 // by every survivor of earlier groups, by the survivors of earlier cells of its group (any
 // anchor) and by the earlier anchors of its own cell.
-__device__ __forceinline__ int tile_rank_cells(bool pass, u64 *s_bal, int n_anchor, int &total)
+__device__ __forceinline__ int tile_rank_cells(bool pass, u64 *s_bal, int n_anchor, int m, int a,
+                                               int &total)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nw = blockDim.x >> 6;
-    const int m = wave / n_anchor, a = wave - m * n_anchor;
+    const int lane = threadIdx.x & 63;
     const u64 bal = __ballot(pass);
-    if (lane == 0) s_bal[wave] = bal;
+    if (lane == 0) s_bal[m * n_anchor + a] = bal;
     __syncthreads();
     const u64 below = lanes_below(lane);
     int rank = 0;
     total = 0;
-    for (int w = 0; w < nw; ++w) {
-        const u64 mk = s_bal[w];
-        const int c = __popcll(mk);
-        const int wm = w / n_anchor, wa = w - wm * n_anchor;
-        if (wm < m) rank += c;
-        else if (wm == m) {
-            rank += __popcll(mk & below);
-            if (wa < a) rank += (int)((mk >> lane) & 1ull);
+#pragma unroll
+    for (int wm = 0; wm < kFrontGroups; ++wm) {
+        for (int wa = 0; wa < n_anchor; ++wa) {
+            const u64 mk = s_bal[wm * n_anchor + wa];
+            const int c = __popcll(mk);
+            total += c;
+            if (wm < m) rank += c;
+            else if (wm == m) {
+                rank += __popcll(mk & below);
+                if (wa < a) rank += (int)((mk >> lane) & 1ull);
+            }
         }
-        total += c;
     }
     return rank;
 }
@@ -236,7 +257,10 @@ __global__ void k_front_heads_v3(HeadsArgs ha, CandBuf cb, float conf, float t_l
         if (i < ha.n_heads && tile >= ha.h[i].tile_begin) h = i;
     const HeadGeom &g = ha.h[h];
     const int n_anchor = blockDim.x / kFrontCells;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave-uniform quantities are made scalar so that the plane base addresses are computed
+    // once on the scalar unit and every load is "scalar base + lane offset"
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = wave / n_anchor, a = wave - m * n_anchor;
     const int C = CS ? CS : ha.C;
     const int V = 5 + C;
@@ -247,15 +271,15 @@ __global__ void k_front_heads_v3(HeadsArgs ha, CandBuf cb, float conf, float t_l
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f;
     float tc[CS ? CS : 1];
     if (active) {
-        const float *p = g.data + ((size_t)(b * g.A + a) * V) * cells + cell;
-        t4 = p[(size_t)4 * cells];
-        t0 = p[0];
-        t1 = p[(size_t)1 * cells];
-        t2 = p[(size_t)2 * cells];
-        t3 = p[(size_t)3 * cells];
+        const float *plane = g.data + ((size_t)(b * g.A + a) * V) * cells;   // scalar
+        t4 = (plane + (size_t)4 * cells)[cell];
+        t0 = plane[cell];
+        t1 = (plane + (size_t)1 * cells)[cell];
+        t2 = (plane + (size_t)2 * cells)[cell];
+        t3 = (plane + (size_t)3 * cells)[cell];
         if (CS) {
 #pragma unroll
-            for (int j = 0; j < (CS ? CS : 1); ++j) tc[j] = p[(size_t)(5 + j) * cells];
+            for (int j = 0; j < (CS ? CS : 1); ++j) tc[j] = (plane + (size_t)(5 + j) * cells)[cell];
         }
     }
     bool pass = active && (t4 >= t_hi);
@@ -264,7 +288,7 @@ __global__ void k_front_heads_v3(HeadsArgs ha, CandBuf cb, float conf, float t_l
         pass = (obj > conf) && (obj != 0.0f);
     }
     int total;
-    const int rank = tile_rank_cells(pass, s_bal, n_anchor, total);
+    const int rank = tile_rank_cells(pass, s_bal, n_anchor, m, a, total);
     if (pass) {
         float *st = s_stage + rank * kStride;
         st[0] = t0; st[1] = t1; st[2] = t2; st[3] = t3; st[4] = t4;
@@ -625,15 +649,18 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kSegThreads) void k_segment_nms(SegArgs s)
+__global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void k_segment_nms(SegArgs s)
 {
     // s_raw: sort keys of segments above kSmallCap (bitonic sort, up to kSortCap keys); for
-    // small segments the pairwise suppression bitmask (kSmallWords x kSmallCap words).
-    // s_small (small segments only): [0, 8(cap+8)) gathered keys, later the sorted slot ids;
-    // [8(cap+8), 16(cap+8)) sorted keys; [16(cap+8), 32(cap+8)) sorted boxes.
-    __shared__ __align__(16) unsigned char s_raw[kSortCap * 8];
-    __shared__ __align__(16) unsigned char s_small[32 * (kSmallCap + 8)];
-    __shared__ int s_tpre[kTileCap];
+    // small segments the triangular pairwise suppression bitmask.
+    // s_small: [0, 8(cap+8)) gathered keys, later the sorted slot ids and box areas;
+    // [8(cap+8), 16(cap+8)) sorted keys; [16(cap+8), 32(cap+8)) the tile-count prefix during
+    // the gather, later the sorted boxes.
+    __shared__ __align__(16) unsigned char s_raw[kRawBytes];
+    __shared__ __align__(16) unsigned char s_small[kSmallBytes];
+    int *s_tpre = reinterpret_cast<int *>(s_small + 16 * (kSmallCap + 8));
+    static_assert(kTileCap * 4 <= 16 * (kSmallCap + 8), "tile prefix must fit the box region");
     __shared__ ChunkShared s_chunk;
     __shared__ int s_cnt[4];   // [0] candidates of lower classes, [1] of this class
     __shared__ int s_scan[kSegWaves];
@@ -762,61 +789,110 @@ __global__ __launch_bounds__(kSegThreads) void k_segment_nms(SegArgs s)
 
     if (K <= kSmallCap) {
         // ---- small segment: rank sort, then the full pairwise suppression bitmask in LDS
-        // (word-major: cmask[w * kSmallCap + j] holds, for column j, the rows 64w..64w+63
-        // that precede j in sorted order and suppress it) and a sweep by wave 0 that needs
-        // no barriers and no IoU arithmetic.
+        // (triangular, word-major: word w of column j >= 64w holds the rows 64w..64w+63 that
+        // precede j in sorted order and suppress it) and a sweep by wave 0 that needs no
+        // barriers and no IoU arithmetic.
         u64 *cmask = reinterpret_cast<u64 *>(s_raw);
         u64 *keys_out = reinterpret_cast<u64 *>(s_small + 8 * (kSmallCap + 8));
         float4 *lbox = reinterpret_cast<float4 *>(s_small + 16 * (kSmallCap + 8));
         int *lslot = reinterpret_cast<int *>(s_small);
+        float *larea = reinterpret_cast<float *>(s_small + 4 * kSmallCap);
         for (int i = K + tid; i < ((K + 7) & ~7); i += kSegThreads) keys_small[i] = ~0ull;
         __syncthreads();
         rank_sort(keys_small, keys_out, K);
         STAMP(3);
         for (int i = tid; i < K; i += kSegThreads) {
             const int slot = (int)(unsigned int)(keys_out[i] & 0xffffffffull);
+            const float4 raw = s.cand_box[ibase + slot];
+            const YpBox bx = {raw.x, raw.y, raw.z, raw.w};
+            const YpPrep pp = yp_prep<MODE>(bx);   // reference mode: corners min/max-normalised
             lslot[i] = slot;
-            lbox[i] = s.cand_box[ibase + slot];
+            lbox[i] = make_float4(pp.lo0, pp.lo1, pp.hi0, pp.hi1);
+            larea[i] = pp.area;
         }
+        const int nwords = (K + 63) >> 6;
         __syncthreads();
         STAMP(4);
-        const int nwords = (K + 63) >> 6;
         const YpThr thr = yp_make_thr(s.thr);
+        const float plus1 = MODE == YP_MODE_YOLOV3 ? 1.0f : 0.0f;
         // all-pairs tile: lanes hold the 64 rows of word w; each wave walks the columns
-        // j >= 64w it owns, four at a time (independent tests, so their latencies overlap)
+        // j >= 64w it owns, kPairUnroll at a time, written stage by stage over the independent
+        // columns so that neighbouring instructions do not depend on each other.  Same
+        // arithmetic and guard bands as yp_suppress_pretest (one-instruction min/max);
+        // undecided lanes take the exact divide-and-compare.
+        constexpr int kPairUnroll = 8;
+        const int wu = __builtin_amdgcn_readfirstlane(wave);
         for (int w = 0; w < nwords; ++w) {
             const int i = (w << 6) + lane;
             const float4 ci = lbox[i < K ? i : 0];
-            const YpBox bi = {ci.x, ci.y, ci.z, ci.w};
-            const YpPrep pi = yp_prep<MODE>(bi);
-            for (int j0 = (w << 6) + wave; j0 < K; j0 += 4 * kSegWaves) {
-                int verdict[4];
-                YpPrep pj[4];
+            const float ai = larea[i < K ? i : 0];
+            const YpPrep pi = {ci.x, ci.y, ci.z, ci.w, ai};
+            u64 *cw = cmask + (w * K - 32 * w * (w - 1)) - (w << 6);   // cw[j], j >= 64w
+            for (int j0 = (w << 6) + wu; j0 < K; j0 += kPairUnroll * kSegWaves) {
+                int verdict[kPairUnroll];
+                int undecided = 0;
+                float4 cj[kPairUnroll];
+                float aj[kPairUnroll], lo0[kPairUnroll], lo1[kPairUnroll], hi0[kPairUnroll],
+                    hi1[kPairUnroll], d0[kPairUnroll], d1[kPairUnroll], inter[kPairUnroll],
+                    uni[kPairUnroll];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < kPairUnroll; ++u) {
                     const int j = j0 + u * kSegWaves;
-                    const float4 cj = lbox[j < K ? j : 0];
-                    const YpBox bj = {cj.x, cj.y, cj.z, cj.w};
-                    pj[u] = yp_prep<MODE>(bj);
-                    const bool test = (i < j) && (j < K);
-                    const int v = yp_suppress_pretest<MODE>(pi, pj[u], thr);
-                    verdict[u] = test ? v : 0;
-                    pairs += test ? 1u : 0u;
-                }
-                bool sup[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    sup[u] = verdict[u] == 1;
-                    if (verdict[u] == 2) sup[u] = yp_suppresses_exact<MODE>(pi, pj[u], thr.thr);
+                    cj[u] = lbox[j < K ? j : 0];
+                    aj[u] = larea[j < K ? j : 0];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < kPairUnroll; ++u) lo0[u] = vmax(ci.x, cj[u].x);
+#pragma unroll
+                for (int u = 0; u < kPairUnroll; ++u) lo1[u] = vmax(ci.y, cj[u].y);
+#pragma unroll
+                for (int u = 0; u < kPairUnroll; ++u) hi0[u] = vmin(ci.z, cj[u].z);
+#pragma unroll
+                for (int u = 0; u < kPairUnroll; ++u) hi1[u] = vmin(ci.w, cj[u].w);
+#pragma unroll
+                for (int u = 0; u < kPairUnroll; ++u) d0[u] = hi0[u] - lo0[u] + plus1;
+#pragma unroll
+                for (int u = 0; u < kPairUnroll; ++u) d1[u] = hi1[u] - lo1[u] + plus1;
+#pragma unroll
+                for (int u = 0; u < kPairUnroll; ++u) d0[u] = vmax(d0[u], 0.0f);
+#pragma unroll
+                for (int u = 0; u < kPairUnroll; ++u) d1[u] = vmax(d1[u], 0.0f);
+#pragma unroll
+                for (int u = 0; u < kPairUnroll; ++u) inter[u] = d0[u] * d1[u];
+#pragma unroll
+                for (int u = 0; u < kPairUnroll; ++u) uni[u] = ai + aj[u] - inter[u];
+#pragma unroll
+                for (int u = 0; u < kPairUnroll; ++u) {
                     const int j = j0 + u * kSegWaves;
-                    const u64 word = __ballot(sup[u]);
-                    if (lane == 0 && j < K) cmask[w * kSmallCap + j] = word;
+                    const bool yes = inter[u] > thr.hi * uni[u];
+                    const bool no = inter[u] < thr.lo * uni[u];
+                    // a union above 1e30 needs no guard: the bands then decide "no", which
+                    // is what the quotient gives
+                    int v = (thr.fast & (uni[u] > 1e-30f) & (yes | no)) ? (yes ? 1 : 0) : 2;
+                    if (MODE == YP_MODE_REFERENCE)
+                        v = ((ai <= 0.0f) | (aj[u] <= 0.0f)) ? ((0.0f > thr.thr) ? 1 : 0) : v;
+                    v = ((i < j) && (j < K)) ? v : 0;
+                    verdict[u] = v;
+                    undecided |= v;
+                }
+                if (undecided & 2) {   // rare: some quotient sits within 2^-20 of the threshold
+#pragma unroll
+                    for (int u = 0; u < kPairUnroll; ++u) {
+                        if (verdict[u] == 2) {
+                            const YpPrep pj = {cj[u].x, cj[u].y, cj[u].z, cj[u].w, aj[u]};
+                            verdict[u] = yp_suppresses_exact<MODE>(pi, pj, thr.thr) ? 1 : 0;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kPairUnroll; ++u) {
+                    const int j = j0 + u * kSegWaves;
+                    const u64 word = __ballot(verdict[u] == 1);
+                    if (lane == 0 && j < K) cw[j] = word;
                 }
             }
         }
+        pairs = tid == 0 ? (unsigned int)((long long)K * (K - 1) / 2) : 0u;
         __syncthreads();
         STAMP(7);
         if (wave == 0) {
@@ -824,14 +900,15 @@ __global__ __launch_bounds__(kSegThreads) void k_segment_nms(SegArgs s)
 #pragma unroll
             for (int w = 0; w < kSmallWords; ++w) keptw[w] = 0ull;
 #pragma unroll
-            for (int cw = 0; cw < kSmallWords; ++cw) {
-                if (cw < nwords && nkept < max_out) {
-                    const int j = (cw << 6) + lane;
+            for (int cwd = 0; cwd < kSmallWords; ++cwd) {
+                if (cwd < nwords && nkept < max_out) {
+                    const int j = (cwd << 6) + lane;
+                    const int jj = j < K ? j : (cwd << 6);
                     bool alive = j < K;
 #pragma unroll
-                    for (int w = 0; w < cw; ++w)
-                        alive = alive && (cmask[w * kSmallCap + (j < K ? j : 0)] & keptw[w]) == 0ull;
-                    const u64 mycol = (j < K) ? cmask[cw * kSmallCap + j] : 0ull;
+                    for (int w = 0; w < cwd; ++w)
+                        alive = alive && (cmask[(w * K - 32 * w * (w - 1)) + jj - (w << 6)] & keptw[w]) == 0ull;
+                    const u64 mycol = (j < K) ? cmask[(cwd * K - 32 * cwd * (cwd - 1)) + jj - (cwd << 6)] : 0ull;
                     // greedy keep set of the chunk as the fixed point of
                     // keep[i] = alive[i] && no kept earlier row of the chunk suppresses i
                     u64 keep = __ballot(alive);
@@ -843,9 +920,10 @@ __global__ __launch_bounds__(kSegThreads) void k_segment_nms(SegArgs s)
                     const int room = max_out - nkept;
                     if (__popcll(keep) > room)
                         keep = __ballot(((keep >> lane) & 1ull) && __popcll(keep & lanes_below(lane)) < room);
-                    keptw[cw] = keep;
+                    keptw[cwd] = keep;
                     if ((keep >> lane) & 1ull)
-                        emit_kept(lslot, nkept + __popcll(keep & lanes_below(lane)), j, lbox[j]);
+                        emit_kept(lslot, nkept + __popcll(keep & lanes_below(lane)), j,
+                                  s.cand_box[ibase + lslot[j]]);
                     nkept += __popcll(keep);
                 }
             }

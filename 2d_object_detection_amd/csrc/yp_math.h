@@ -20,14 +20,17 @@ YP_HD uint32_t yp_f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 // exp(x): k = floor(x*log2(e) + 0.5), r = x - k*ln2 (two-term ln2), degree-5 minimax tail
 // in Horner form with fma (Cephes expf coefficients), scaled by 2^k in two exact steps so
-// that both factors are normal numbers.  Max error 0.98 ulp on [-104, 88.7].
+// that both factors are normal numbers.  Max error 0.98 ulp on [-104, 88.7].  Written
+// without branches: the argument is clamped into the finite range for the arithmetic and
+// the overflow / underflow / NaN results are selected at the end (in-range arguments go
+// through exactly the operations listed above).
 YP_HD float yp_exp(float x)
 {
-    if (x != x) return x;
-    if (x > 88.72283935546875f) return __builtin_inff();
-    if (x < -103.97207641601562f) return 0.0f;
-    float kf = __builtin_floorf(__builtin_fmaf(x, 1.44269504088896341f, 0.5f));
-    float r = __builtin_fmaf(kf, -0.693359375f, x);
+    const float hi = 88.72283935546875f, lo = -103.97207641601562f;
+    float xc = x > hi ? hi : x;
+    xc = xc < lo ? lo : xc;
+    float kf = __builtin_floorf(__builtin_fmaf(xc, 1.44269504088896341f, 0.5f));
+    float r = __builtin_fmaf(kf, -0.693359375f, xc);
     r = __builtin_fmaf(kf, 2.12194440e-4f, r);
     float p = 1.9875691500e-4f;
     p = __builtin_fmaf(p, r, 1.3981999507e-3f);
@@ -38,12 +41,15 @@ YP_HD float yp_exp(float x)
     float r2 = r * r;
     p = __builtin_fmaf(p, r2, r);
     p = p + 1.0f;
-    int k = (int)kf;
+    int k = (x == x) ? (int)kf : 0;
     int k1 = k >> 1;
     int k2 = k - k1;
     float s1 = yp_bits2f((uint32_t)(k1 + 127) << 23);
     float s2 = yp_bits2f((uint32_t)(k2 + 127) << 23);
-    return (p * s1) * s2;
+    float y = (p * s1) * s2;
+    y = x > hi ? __builtin_inff() : y;
+    y = x < lo ? 0.0f : y;
+    return (x == x) ? y : x;
 }
 
 YP_HD float yp_sigmoid(float x) { return 1.0f / (1.0f + yp_exp(-x)); }
@@ -164,7 +170,8 @@ YP_HD int yp_suppress_pretest(const YpPrep &p, const YpPrep &q, const YpThr &t)
     const float uni = p.area + q.area - inter;
     const bool yes = inter > t.hi * uni;
     const bool no = inter < t.lo * uni;
-    const bool decided = t.fast & (uni > 1e-30f) & (uni < 1e30f) & (yes | no);
+    // (no upper guard on the union: above 1e30 the bands decide "no", as the quotient does)
+    const bool decided = t.fast & (uni > 1e-30f) & (yes | no);
     int v = decided ? (yes ? 1 : 0) : 2;
     if (MODE != 0) {
         const bool degenerate = (p.area <= 0.0f) | (q.area <= 0.0f);

@@ -208,11 +208,12 @@ class YoloV3Post:
             hs.append(_head_desc(h, self.inp_dim, a, self.num_classes))
         return (_lib.YpHead * len(hs))(*hs)
 
-    def run(self, heads):
+    def run(self, heads, stream=None):
         """Enqueue decode + filter + NMS; returns (rows (cap, 8), count (1,) int32) on the
-        device.  rows[:count] are valid once the stream has executed.  The validated head
-        descriptors are cached per set of input buffers, so a serving loop that reuses its
-        input buffers pays one C call per batch."""
+        device.  rows[:count] are valid once the stream has executed.  ``stream`` is a
+        torch.cuda.Stream (default: the current stream).  The validated head descriptors
+        are cached per set of input buffers, so a serving loop that reuses its input buffers
+        pays one C call per batch."""
         key = tuple(h.data_ptr() for h in heads)
         descs = self._desc_cache.get(key)
         if descs is None:
@@ -220,7 +221,7 @@ class YoloV3Post:
             if len(self._desc_cache) > 64:
                 self._desc_cache.clear()
             self._desc_cache[key] = descs
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        stream = (torch.cuda.current_stream(self.device) if stream is None else stream).cuda_stream
         rc = self._detect(descs, len(descs), self._params_ref, self._out_ptr, self.cap,
                           self._count_ptr, self._stats_ptr, self._ws_ptr, self._ws_bytes, stream)
         if rc != 0:

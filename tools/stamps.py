@@ -49,3 +49,8 @@ dc = raw[:, 16 + 5] - raw[:, 16 + 4]
 dt = (raw[:, 5] - raw[:, 4]) * 10e-9
 print("shader clock during the NMS phase: %.0f MHz (cycles / wall time, median over segments)"
       % float(np.median(dc / dt) / 1e6))
+
+it = raw[:, 24:32]
+print("pair-matrix iteration starts of wave 0 (shader cycles after the phase start, median):")
+print([int(np.median(it[:, k] - raw[:, 16 + 4])) for k in range(8) if np.median(it[:, k]) > 0],
+      "phase end", int(np.median(raw[:, 16 + 7] - raw[:, 16 + 4])))
