@@ -38,6 +38,8 @@ CONFIGS = {
     "cfg2": (64, 416, 0.5, 0.4, 1, "batch 64 at 416x416 (10,647 anchors/image), conf 0.5 / NMS 0.4"),
     "cfg3": (32, (1280, 1920), 0.5, 0.4, 2,
              "batch 32 at 1920x1280 (151,200 anchors/image), conf 0.5 / NMS 0.4"),
+    "cfg3x2": (64, (1280, 1920), 0.5, 0.4, 2,
+               "batch 64 at 1920x1280 (387 MB of heads, larger than the 256 MiB Infinity Cache)"),
     "cfg4": (64, 608, 0.5, 0.4, 3, "batch 64 per GPU at 608x608 (22,743 anchors/image), conf 0.5 / NMS 0.4"),
     "cfg5": (32, (1280, 1920), 0.001, 0.4, 4,
              "batch 32 per GPU at 1920x1280, conf 0.001 / NMS 0.4 (near-all survive)"),
@@ -84,7 +86,7 @@ def main():
     ap.add_argument("--clustered", action="store_true",
                     help="overlapping boxes around object centres instead of i.i.d. boxes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="independent batches in flight (engines x HIP streams); 1 = latency mode")
     args = ap.parse_args()
 
@@ -96,13 +98,18 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU path to benchmark)")
+    local_rank %= torch.cuda.device_count()      # (rehearsals may put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("YP_BENCH_BACKEND", "nccl")   # nccl = RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     batch, inp_dim, conf, nms, seed, desc = CONFIGS[args.config]
     cpu_heads, heads = make_device_heads(batch, inp_dim, seed + 100 * rank, dev, args.clustered)
@@ -112,16 +119,32 @@ def main():
     # are independent, so the decode of batch i+1 overlaps the NMS of batch i.  With ranks
     # exchanging results, each engine writes straight into the payload of its gather buffer.
     n_eng = max(1, args.in_flight)
-    gathers, engines = [], []
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_eng)]
-    for _ in range(n_eng):
-        if world > 1:
-            g = dsb.PaddedRowGather(batch * 2048, 8, dev)   # per-rank capacity, rows of 32 B
-            gathers.append(g)
-            engines.append(util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
-                                           batch_offset=rank * batch, out=g.rows))
-        else:
-            engines.append(util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev))
+    gathers, engines = [], []
+
+    def build(gather_cap):
+        gathers.clear()
+        engines.clear()
+        for _ in range(n_eng):
+            if world > 1:
+                g = dsb.PaddedRowGather(gather_cap, 8, dev)     # rows of 32 B
+                gathers.append(g)
+                engines.append(util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
+                                               batch_offset=rank * batch, out=g.rows))
+            else:
+                engines.append(util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev))
+
+    gather_cap = batch * 2048
+    build(gather_cap)
+    if world > 1:
+        # size the fixed-capacity exchange from one real batch: largest per-rank detection
+        # count over all ranks + 25 %, so the collective moves little more than the payload
+        _, cnt = engines[0].run(heads)
+        torch.cuda.synchronize()
+        cmax = cnt.to(torch.int64).clone()
+        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+        gather_cap = max(1024, -(-int(cmax.item()) * 5 // 4 // 1024) * 1024)
+        build(gather_cap)
     pending = [None] * n_eng
     torch.cuda.synchronize()
 
@@ -180,13 +203,23 @@ def main():
         drain()
         gathered, counts = gathers[(args.steps - 1) % n_eng].unpack()
         assert len(counts) == world
+        gather_overflow = max(counts) > gather_cap
         dist.barrier()
 
     if rank == 0:
         n_anchors = batch * rows_per_image
-        tiles = batch * sum(-(-(gh * gw) // 64) for gh, gw in engines[0].grids)
+        tiles = batch * sum(-(-(gh * gw) // 128) for gh, gw in engines[0].grids)
+        # algorithmic bytes of the front kernel: every anchor's 10 f32 logits read once,
+        # 28 B written per survivor (box 16, objectness 4, class score 4, class id 4) and one
+        # int32 survivor count per 128-cell tile
         alg_bytes = 40.0 * n_anchors + 28.0 * total_surv + 4.0 * tiles
         achieved = alg_bytes / (front_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_front_kernel_traffic.json")
+        if os.path.exists(tfile) and not args.clustered:
+            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this
+            # same command, collected offline and committed; see the file for the correction
+            traffic = json.load(open(tfile)).get(args.config, {}).get("traffic_bytes")
         out = {
             "metric": "decode+NMS images/sec",
             "value": round(world * batch * args.steps / elapsed, 1),
@@ -213,7 +246,7 @@ def main():
                        "host_enqueue_us_per_step": round(t_enqueued / args.steps * 1e6, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_front_heads_v3 (decode+filter+compaction)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes": int(alg_bytes),
                          "kernel_ms": round(front_ms, 5)},
             "kernels_ms": {"front": round(front_ms, 5), "segment_nms": round(nms_ms, 5),
@@ -222,6 +255,10 @@ def main():
                            "nms_iou_pairs_per_s": round(float(pairs.astype(np.int64).sum())
                                                         / (nms_ms * 1e-3), 1)},
         }
+        if world > 1:
+            out["config"]["gather_rows_capacity_per_rank"] = gather_cap
+            out["config"]["gather_rows_last_step"] = counts
+            out["config"]["gather_overflow"] = bool(gather_overflow)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cpu_heads, inp_dim, conf, nms)
         print(json.dumps(out), flush=True)

@@ -322,3 +322,107 @@ def test_ref_ragged_counts_pack_as_object_array(pkg, dev, monkeypatch):
     boxes, scores, classes, index = DN.detect(pred.to(dev))
     assert boxes.dtype == object and boxes.shape == (3,) and boxes.size == 3
     assert np.asarray(boxes[1]).shape == (0, 4)
+
+
+# ----------------------------------------------------------- BASELINE.json full-size configs
+
+def _check_v3_properties(pkg, dev, got, nms, C):
+    """Size-independent properties of a write_results output: ordering, and NMS idempotence
+    (running the NMS again on the kept rows keeps every one of them)."""
+    util = pkg.util
+    if got.shape[0] == 0:
+        return
+    img, cls, obj = got[:, 0], got[:, 7], got[:, 5]
+    key = img.astype(np.int64) * C + cls.astype(np.int64)
+    assert np.all(np.diff(key) >= 0)                               # image, then class ascending
+    same = np.diff(key) == 0
+    assert np.all(np.diff(obj)[same] <= 0)                         # objectness descending inside
+    # rebuild decoded rows from the kept boxes and run the GPU NMS again: nothing may go
+    B = int(img.max()) + 1
+    per = [got[img == b] for b in range(B)]
+    n = max(len(p) for p in per)
+    rows = np.zeros((B, n, 5 + C), np.float32)
+    for b, p in enumerate(per):
+        k = len(p)
+        rows[b, :k, 0] = (p[:, 1] + p[:, 3]) / 2
+        rows[b, :k, 1] = (p[:, 2] + p[:, 4]) / 2
+        rows[b, :k, 2] = p[:, 3] - p[:, 1]
+        rows[b, :k, 3] = p[:, 4] - p[:, 2]
+        rows[b, :k, 4] = p[:, 5]
+        rows[b, np.arange(k), 5 + p[:, 7].astype(int)] = 1.0
+    again = util.write_results(torch.from_numpy(rows).to(dev), 1e-9, C, nms + 0.02)
+    assert again.shape[0] == got.shape[0]
+
+
+@pytest.mark.parametrize("name,B,inp_dim,conf,nms,seed,clustered", [
+    ("cfg2", 64, 416, 0.5, 0.4, 1, False),               # batch 64 at 416x416
+    ("cfg2-clustered", 64, 416, 0.5, 0.4, 1, True),
+    ("cfg3", 32, (1280, 1920), 0.5, 0.4, 2, False),      # Waymo front camera, batch 32
+    ("cfg4-shard", 64, 608, 0.5, 0.4, 3, False),         # one GPU's share of batch 512 at 608
+    ("cfg5-slice", 2, (1280, 1920), 0.001, 0.4, 4, False),  # worst-case dense NMS, 2 images
+])
+def test_v3_full_size_configs_match_oracle(pkg, dev, name, B, inp_dim, conf, nms, seed, clustered):
+    """The BASELINE.json configurations at full size (cfg5 on a 2-image slice: the oracle's
+    O(K^2) loop over ~30k boxes per class takes seconds per image): every output bit equals
+    the oracle's, plus the size-independent properties."""
+    syn, util = pkg.synthetic, pkg.util
+    chunks = [syn.make_heads(min(16, B - lo), inp_dim, 5, seed=seed * 1000 + lo, clustered=clustered)
+              for lo in range(0, B, 16)]
+    heads = [torch.cat([c[h] for c in chunks], 0).contiguous() for h in range(3)]
+    want, surv, _ = v3_oracle(heads, inp_dim, syn.YOLOV3_ANCHORS, 5, conf, nms)
+    eng = util.YoloV3Post(B, inp_dim, 5, conf, nms, device=dev)
+    got = eng.detect([h.to(dev) for h in heads]).cpu().numpy()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert np.array_equal(got, want), name
+    s_surv, s_kept, _ = eng.segment_stats()
+    assert np.array_equal(s_surv.sum(1), surv)
+    _check_v3_properties(pkg, dev, got, nms, 5)
+
+
+def test_ref_batch16_default_config(pkg, dev):
+    """The reference's own configuration (params.py defaults, batch 16) through both the
+    two-call surface and the fused call, on relu'd heads as the network produces them."""
+    P, DN = pkg.params, pkg.DetectNet
+    pred = pkg.synthetic.make_reference_head(16, seed=77, relu=True, obj_mean=0.5)
+    want = ref_oracle(pred.numpy(), P)
+    assert_ref_equal(DN.filter_boxes(DN.predict_transform(pred.to(dev))), want, 16)
+    assert_ref_equal(DN.detect(pred.to(dev)), want, 16)
+    for b in range(16):                     # kept boxes pairwise at or below the IoU threshold
+        bx = want[0][b]
+        for i in range(len(bx)):
+            for j in range(i):
+                assert not oracle.tf_iou(bx[j], bx[i]) > P.nms_conf
+
+
+# ------------------------------------------------------------------ committed golden vectors
+
+def test_gpu_matches_committed_golden_vectors(pkg, dev):
+    """The HIP path against the data files under tests/golden (inputs + expected outputs),
+    so the result is pinned to committed bytes and not only to a live run of the oracle."""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    syn, util, P, DN = pkg.synthetic, pkg.util, pkg.params, pkg.DetectNet
+    g = np.load(os.path.join(gold, "yolov3_96.npz"))
+    heads = [torch.from_numpy(g["head%d" % i]).to(dev) for i in range(3)]
+    rows = util.predict_transform_heads(heads, 96, syn.YOLOV3_ANCHORS, 5)
+    assert np.array_equal(rows.cpu().numpy(), g["rows"])
+    det = util.YoloV3Post(2, 96, 5, float(g["conf"]), float(g["nms"]), device=dev).detect(heads)
+    assert np.array_equal(det.cpu().numpy(), g["det"])
+    assert np.array_equal(util.write_results(rows, float(g["conf"]), 5, float(g["nms"])).cpu().numpy(), g["det"])
+
+    g = np.load(os.path.join(gold, "reference_13x13.npz"))
+    pred = torch.from_numpy(g["pred"]).to(dev)
+    c, w, o, p = DN.predict_transform(pred)
+    for got, key in ((c, "center"), (w, "wh"), (o, "obj"), (p, "cls")):
+        assert np.array_equal(got.cpu().numpy(), g[key])
+    boxes, scores, classes, index = DN.detect(pred)
+    assert np.array_equal(np.concatenate([np.asarray(b).reshape(-1, 4) for b in boxes]), g["boxes"])
+    assert np.array_equal(np.concatenate([np.asarray(x) for x in scores]), g["scores"])
+    assert np.array_equal(np.concatenate([np.asarray(x) for x in classes]), g["classes"])
+    assert np.array_equal(np.concatenate([np.asarray(x) for x in index]), g["index"])
+    assert np.array_equal(DN.last_survivor_counts.cpu().numpy(), g["surv"])
+
+    g = np.load(os.path.join(gold, "nms_edge_cases.npz"))
+    rows = torch.from_numpy(g["rows"]).to(dev)
+    for name, thr in (("t04", 0.4), ("t13", 1.0 / 3.0), ("t05", 0.5), ("t10", 1.0)):
+        assert np.array_equal(util.write_results(rows, 0.5, 3, thr).cpu().numpy(), g["det_" + name])
