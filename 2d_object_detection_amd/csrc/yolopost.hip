@@ -333,6 +333,121 @@ __global__ void k_front_heads_v3(HeadsArgs ha, CandBuf cb, float conf, float t_l
     if (threadIdx.x == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = total;
 }
 
+// One-wave variant of the heads front kernel for a compile-time class count CS and anchor
+// count NA: the workgroup is a single wave that owns the tile's 128 cells x NA anchors, two
+// CONSECUTIVE cells per lane, so a channel load is one 8-byte access per lane (512 B per
+// wave instruction) whenever the plane slice is 8-byte aligned (always for even grids).  All
+// 2*NA*(5+CS) values of a lane are requested before anything is consumed, the ballots that
+// rank the survivors are wave-local, and the LDS staging between the two phases is written
+// and read by the same wave -- so the kernel has no barrier at all and a quarter of the
+// waves of the generic kernel above.  Same slots, same results.
+template <int CS, int NA>
+__global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBuf cb, float conf,
+                                                            float t_lo, float t_hi)
+{
+    extern __shared__ float s_stage[];
+    constexpr int kStride = 6 + CS;
+    constexpr int V = 5 + CS;
+    static_assert(kFrontCells == 128, "two cells per lane");
+    const int tile = blockIdx.x, b = blockIdx.y;
+    int h = 0;
+#pragma unroll
+    for (int i = 1; i < YP_MAX_HEADS; ++i)
+        if (i < ha.n_heads && tile >= ha.h[i].tile_begin) h = i;
+    const HeadGeom &g = ha.h[h];
+    const int lane = threadIdx.x;
+    const int cells = g.gh * g.gw;
+    const int cell0 = (tile - g.tile_begin) * kFrontCells;
+    const int cell = cell0 + 2 * lane;            // this lane's cells: cell, cell + 1
+    const bool in0 = cell < cells, in1 = cell + 1 < cells;
+
+    float t[2][NA][V];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const float *plane0 = g.data + ((size_t)(b * NA + a) * V) * cells + cell0;   // scalar
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float *pl = plane0 + (size_t)v * cells;
+            const bool wide = ((reinterpret_cast<uintptr_t>(pl) & 7) == 0) && (cell0 + kFrontCells <= cells);
+            if (wide) {     // wave-uniform: whole slice present and 8-byte aligned
+                const float2 q = reinterpret_cast<const float2 *>(pl)[lane];
+                t[0][a][v] = q.x;
+                t[1][a][v] = q.y;
+            } else {
+                t[0][a][v] = in0 ? pl[2 * lane] : 0.0f;
+                t[1][a][v] = in1 ? pl[2 * lane + 1] : 0.0f;
+            }
+        }
+    }
+    bool pass[2][NA];
+    u64 bal[2][NA];
+    int total = 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const bool in = c ? in1 : in0;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            bool p = in && (t[c][a][4] >= t_hi);
+            if (in && !p && !(t[c][a][4] <= t_lo)) {
+                const float obj = yp_sigmoid(t[c][a][4]);
+                p = (obj > conf) && (obj != 0.0f);
+            }
+            pass[c][a] = p;
+            bal[c][a] = __ballot(p);
+            total += __popcll(bal[c][a]);
+        }
+    }
+    // rank in anchor order (row = cell * NA + anchor): everything of the lanes below, then this
+    // lane's earlier (cell, anchor) pairs
+    const u64 below = lanes_below(lane);
+    int rank = 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) rank += __popcll(bal[c][a] & below);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            if (pass[c][a]) {
+                float *st = s_stage + rank * kStride;
+#pragma unroll
+                for (int v = 0; v < 5; ++v) st[v] = t[c][a][v];
+                reinterpret_cast<int *>(st)[5] = (a << 24) | (cell + c);
+#pragma unroll
+                for (int j = 0; j < CS; ++j) st[6 + j] = t[c][a][5 + j];
+            }
+            rank += pass[c][a] ? 1 : 0;
+        }
+    }
+    // single wave: its LDS writes above reach the LDS before its reads below (in-order queue);
+    // the wavefront-scope fence only stops the compiler from moving them across each other
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int r = lane; r < total; r += 64) {
+        const float *st = s_stage + r * kStride;
+        const int packed = reinterpret_cast<const int *>(st)[5];
+        const int sa = packed >> 24, scell = packed & 0xffffff;
+        const int row = scell / g.gw, col = scell - row * g.gw;
+        const float obj = yp_sigmoid(st[4]);
+        const float cx = (yp_sigmoid(st[0]) + (float)col) * g.sx;
+        const float cy = (yp_sigmoid(st[1]) + (float)row) * g.sy;
+        const float w = (yp_exp(st[2]) * g.anc[2 * sa + 0]) * g.sx;
+        const float hgt = (yp_exp(st[3]) * g.anc[2 * sa + 1]) * g.sy;
+        float best = yp_sigmoid(st[6]);
+        int bi = 0;
+#pragma unroll
+        for (int j = 1; j < CS; ++j) {
+            const float sc = yp_sigmoid(st[6 + j]);
+            if (sc > best) { best = sc; bi = j; }
+        }
+        const float hw = w * 0.5f, hh = hgt * 0.5f;
+        YpBox bx = {cx - hw, cy - hh, cx + hw, cy + hh};
+        store_cand(cb, ((size_t)b * cb.tpi + tile) * cb.ts + r, bx, obj + 0.0f, best, bi);
+    }
+    if (lane == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = total;
+}
+
 // ---------------------------------------------------------------- front: reference head
 // Thread t <-> row n = tile*256 + t of image b; a row is the V contiguous floats of one
 // (row, col, anchor) (detect_net.py:153).
@@ -950,6 +1065,7 @@ void k_segment_nms(SegArgs s)
         __syncthreads();
         if (in_lds) bitonic_sort(keys_in, n_pad);
         else bitonic_sort(gdst, n_pad);
+        STAMP(3);
         float4 *gbox = s.sbox + reg;
         int *gslot = s.sslot + reg;
         unsigned char *grem = s.removed + reg;
@@ -960,6 +1076,7 @@ void k_segment_nms(SegArgs s)
             grem[i] = 0;
         }
         __syncthreads();
+        STAMP(4);
         sslot_final = gslot;
         nkept = nms_chunks<MODE>(gbox, grem, K, yp_make_thr(s.thr), max_out, s_chunk, pairs,
                                  [&](int m, int sp, const float4 &bx) { emit_kept(gslot, m, sp, bx); });
@@ -1418,7 +1535,13 @@ int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params, f
     float t_lo, t_hi;
     logit_band(params->conf_thr, &t_lo, &t_hi);
     prof_mark(st, 0);
-    if (params->num_classes == 5)
+    bool all_three = true;
+    for (int i = 0; i < n_heads; ++i) all_three = all_three && heads[i].num_anchors == 3;
+    if (params->num_classes == 5 && all_three)
+        hipLaunchKernelGGL((k_front_heads_v3_wave<5, 3>), grid, dim3(64),
+                           (size_t)ts * (6 + 5) * sizeof(float), st, ha, cb, params->conf_thr, t_lo,
+                           t_hi);
+    else if (params->num_classes == 5)
         hipLaunchKernelGGL(k_front_heads_v3<5>, grid, block, (size_t)ts * (6 + 5) * sizeof(float), st,
                            ha, cb, params->conf_thr, t_lo, t_hi);
     else
