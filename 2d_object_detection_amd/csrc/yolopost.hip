@@ -61,6 +61,7 @@ struct HeadsArgs {
     int tpi;   // tiles per image
     int C;     // classes
     int N;     // rows per image over all heads
+    unsigned long long *dbg;  // diagnostic builds only (YP_STAMPS)
 };
 
 struct AnchorTable {
@@ -356,29 +357,44 @@ __global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBu
         if (i < ha.n_heads && tile >= ha.h[i].tile_begin) h = i;
     const HeadGeom &g = ha.h[h];
     const int lane = threadIdx.x;
+#ifdef YP_STAMPS
+    const size_t dbg_blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (lane == 0 && ha.dbg) ha.dbg[dbg_blk * 4 + 0] = wall_clock64();
+#endif
     const int cells = g.gh * g.gw;
     const int cell0 = (tile - g.tile_begin) * kFrontCells;
     const int cell = cell0 + 2 * lane;            // this lane's cells: cell, cell + 1
     const bool in0 = cell < cells, in1 = cell + 1 < cells;
 
     float t[2][NA][V];
+    // the objectness planes are requested first: the filter and the ranking only need them,
+    // so they run while the other 9 channels of every anchor are still in flight
+    auto load_channel = [&](int a, int v) {
+        const float *pl = g.data + ((size_t)(b * NA + a) * V + v) * cells + cell0;   // scalar
+        const bool wide = ((reinterpret_cast<uintptr_t>(pl) & 7) == 0) && (cell0 + kFrontCells <= cells);
+        if (wide) {     // wave-uniform: whole slice present and 8-byte aligned
+            const float2 q = reinterpret_cast<const float2 *>(pl)[lane];
+            t[0][a][v] = q.x;
+            t[1][a][v] = q.y;
+        } else {
+            t[0][a][v] = in0 ? pl[2 * lane] : 0.0f;
+            t[1][a][v] = in1 ? pl[2 * lane + 1] : 0.0f;
+        }
+    };
+#pragma unroll
+    for (int a = 0; a < NA; ++a) load_channel(a, 4);
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-        const float *plane0 = g.data + ((size_t)(b * NA + a) * V) * cells + cell0;   // scalar
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            const float *pl = plane0 + (size_t)v * cells;
-            const bool wide = ((reinterpret_cast<uintptr_t>(pl) & 7) == 0) && (cell0 + kFrontCells <= cells);
-            if (wide) {     // wave-uniform: whole slice present and 8-byte aligned
-                const float2 q = reinterpret_cast<const float2 *>(pl)[lane];
-                t[0][a][v] = q.x;
-                t[1][a][v] = q.y;
-            } else {
-                t[0][a][v] = in0 ? pl[2 * lane] : 0.0f;
-                t[1][a][v] = in1 ? pl[2 * lane + 1] : 0.0f;
-            }
-        }
+        for (int v = 0; v < V; ++v)
+            if (v != 4) load_channel(a, v);
     }
+#ifdef YP_STAMPS
+    if (lane == 0 && ha.dbg) {
+        asm volatile("" ::"v"(t[0][0][4]), "v"(t[1][NA - 1][4]));
+        ha.dbg[dbg_blk * 4 + 1] = wall_clock64();
+    }
+#endif
     bool pass[2][NA];
     u64 bal[2][NA];
     int total = 0;
@@ -424,6 +440,9 @@ __global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBu
     // the wavefront-scope fence only stops the compiler from moving them across each other
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#ifdef YP_STAMPS
+    if (lane == 0 && ha.dbg) ha.dbg[dbg_blk * 4 + 2] = wall_clock64();
+#endif
     for (int r = lane; r < total; r += 64) {
         const float *st = s_stage + r * kStride;
         const int packed = reinterpret_cast<const int *>(st)[5];
@@ -446,6 +465,9 @@ __global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBu
         store_cand(cb, ((size_t)b * cb.tpi + tile) * cb.ts + r, bx, obj + 0.0f, best, bi);
     }
     if (lane == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = total;
+#ifdef YP_STAMPS
+    if (lane == 0 && ha.dbg) ha.dbg[dbg_blk * 4 + 3] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------- front: reference head
@@ -1210,6 +1232,7 @@ __global__ void k_bbox_iou(const float *box1, const float *boxes2, int m, int ro
 
 constexpr size_t kAlign = 256;
 unsigned long long *g_dbg = nullptr;  // set only through yp_debug_set_stamps (diagnostic build)
+unsigned long long *g_dbg_front = nullptr;
 
 struct Workspace {
     float4 *cand_box;
@@ -1299,6 +1322,7 @@ int heads_geometry(const YpHead *heads, int n_heads, int C, int cells_per_tile, 
     }
     for (int i = n_heads; i < YP_MAX_HEADS; ++i) ha->h[i] = ha->h[0];
     if (tiles > (1ll << 22) || rows > (1ll << 28)) return YP_ERR_UNSUPPORTED;
+    ha->dbg = nullptr;
     ha->n_heads = n_heads;
     ha->tpi = (int)tiles;
     ha->C = C;
@@ -1391,9 +1415,11 @@ int finish_v3(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, f
               long long cap, int32_t *out_count, int32_t *stats, hipStream_t st)
 {
     const int n_seg = p->batch * p->num_classes;
+    const int stages = p->reserved ? p->reserved : 7;   // benchmarking: run a subset of the stages
     SegArgs s = make_seg_args(w, p, spi, tpi, ts, 1);
     s.max_out = p->max_out;
-    hipLaunchKernelGGL(k_segment_nms<YP_MODE_YOLOV3>, dim3(n_seg), dim3(kSegThreads), 0, st, s);
+    if (stages & 2)
+        hipLaunchKernelGGL(k_segment_nms<YP_MODE_YOLOV3>, dim3(n_seg), dim3(kSegThreads), 0, st, s);
     prof_mark(st, 2);
     GatherArgs g = {};
     g.n_seg = n_seg;
@@ -1412,7 +1438,7 @@ int finish_v3(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, f
     g.cap = cap;
     g.out_count = out_count;
     g.stats = stats;
-    hipLaunchKernelGGL(k_gather_rows, dim3(n_seg), dim3(256), 0, st, g);
+    if (stages & 4) hipLaunchKernelGGL(k_gather_rows, dim3(n_seg), dim3(256), 0, st, g);
     prof_mark(st, 3);
     prof_next();
     return (int)hipGetLastError();
@@ -1535,9 +1561,12 @@ int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params, f
     float t_lo, t_hi;
     logit_band(params->conf_thr, &t_lo, &t_hi);
     prof_mark(st, 0);
+    ha.dbg = g_dbg_front;
     bool all_three = true;
     for (int i = 0; i < n_heads; ++i) all_three = all_three && heads[i].num_anchors == 3;
-    if (params->num_classes == 5 && all_three)
+    if (params->reserved && !(params->reserved & 1)) {
+        // benchmarking: the front stage is skipped (the workspace keeps the previous candidates)
+    } else if (params->num_classes == 5 && all_three)
         hipLaunchKernelGGL((k_front_heads_v3_wave<5, 3>), grid, dim3(64),
                            (size_t)ts * (6 + 5) * sizeof(float), st, ha, cb, params->conf_thr, t_lo,
                            t_hi);
@@ -1674,6 +1703,12 @@ int yp_filter_boxes_reference(const float *d_center, const float *d_wh, const fl
 int yp_debug_set_stamps(void *d_buf)
 {
     g_dbg = static_cast<unsigned long long *>(d_buf);
+    return YP_OK;
+}
+/* 4 u64 stamps per workgroup of the heads front kernel (start, loaded, ranked, end) */
+int yp_debug_set_front_stamps(void *d_buf)
+{
+    g_dbg_front = static_cast<unsigned long long *>(d_buf);
     return YP_OK;
 }
 #endif

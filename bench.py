@@ -197,6 +197,25 @@ def main():
     front_ms, nms_ms, gather_ms, calls = _lib.profile_stop()
     torch.cuda.synchronize()
 
+    # the front kernel alone, as a train of launches between two events on one stream: its
+    # launch-to-launch period (kernel + dispatch gap), closer to a profiler's kernel duration
+    # than the per-call event intervals above, which also contain the dependent-launch latency
+    eng0 = engines[0]
+    eng0.params.reserved = 1
+    ntrain = 50
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        eng0.run(heads)
+    ev0.record()
+    for _ in range(ntrain):
+        eng0.run(heads)
+    ev1.record()
+    torch.cuda.synchronize()
+    front_train_ms = ev0.elapsed_time(ev1) / ntrain
+    eng0.params.reserved = 0
+    eng0.run(heads)
+    torch.cuda.synchronize()
+
     surv, kept, pairs = engines[0].segment_stats()
     total_surv, total_kept = int(surv.sum()), int(kept.sum())
     if world > 1:
@@ -213,7 +232,7 @@ def main():
         # 28 B written per survivor (box 16, objectness 4, class score 4, class id 4) and one
         # int32 survivor count per 128-cell tile
         alg_bytes = 40.0 * n_anchors + 28.0 * total_surv + 4.0 * tiles
-        achieved = alg_bytes / (front_ms * 1e-3) / 1e9
+        achieved = alg_bytes / (front_train_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01_front_kernel_traffic.json")
         if os.path.exists(tfile) and not args.clustered:
@@ -248,7 +267,10 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes": int(alg_bytes),
-                         "kernel_ms": round(front_ms, 5)},
+                         "kernel_ms": round(front_train_ms, 5),
+                         "kernel_ms_method": "HIP events around a train of %d launches of this "
+                                             "kernel on its stream" % ntrain,
+                         "kernel_ms_in_pipeline": round(front_ms, 5)},
             "kernels_ms": {"front": round(front_ms, 5), "segment_nms": round(nms_ms, 5),
                            "gather": round(gather_ms, 5), "calls": calls,
                            "nms_iou_pairs": int(pairs.astype(np.int64).sum()),

@@ -84,7 +84,9 @@ typedef struct YpParams {
     float im_h;           /* YP_MODE_REFERENCE: params.im_height */
     float im_w;           /* YP_MODE_REFERENCE: params.im_width */
     int32_t batch_offset; /* YP_MODE_YOLOV3: added to the image index written in column 0 */
-    int32_t reserved;
+    int32_t reserved;     /* 0 = run every stage.  Benchmarks of yp_detect_yolov3 may set a
+                             stage mask (1 front, 2 segment NMS, 4 gather) to time one kernel
+                             in isolation; later stages then reuse the workspace as it is. */
 } YpParams;
 
 int yp_version(void);
