@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "yp_detect_reference_workspace_bytes", "yp_detect_reference",
     "yp_rows_workspace_bytes", "yp_write_results", "yp_filter_boxes_reference",
     "yp_bbox_iou", "yp_profile_start", "yp_profile_stop",
+    "yp_encode_true_box_grid", "yp_true_box_grid_workspace_bytes", "yp_decode_true_box_grid",
 )
 
 
@@ -109,6 +110,13 @@ def load():
     dp = ctypes.POINTER(ctypes.c_double)
     L.yp_profile_stop.restype = i32
     L.yp_profile_stop.argtypes = [dp, dp, dp, ctypes.POINTER(ctypes.c_int)]
+    L.yp_encode_true_box_grid.restype = i32
+    L.yp_encode_true_box_grid.argtypes = [vp, vp, i32, i32, i32, i32, fp, i32, i32, vp, vp, vp]
+    L.yp_true_box_grid_workspace_bytes.restype = sz
+    L.yp_true_box_grid_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.yp_decode_true_box_grid.restype = i32
+    L.yp_decode_true_box_grid.argtypes = [vp, i32, i32, i32, i32, fp, i32, i32, vp, vp, vp, i64, vp,
+                                          vp, sz, vp]
     _lib = L
     return L
 

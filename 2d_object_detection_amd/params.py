@@ -23,6 +23,7 @@ grid_height = int(scaled_height // grid_stride)   # params.py:29
 grid_width = int(scaled_width // grid_stride)     # params.py:30
 num_classes = 5           # params.py:31
 pred_vec_len = 5 + num_classes                    # params.py:32
+true_vec_len = 5                                  # params.py:33
 
 # set True to reproduce the reference's "max score in batch" print (detect_net.py:110);
 # it costs a device-to-host synchronisation inside filter_boxes, so it is off by default.

@@ -167,6 +167,37 @@ int yp_filter_boxes_reference(const float *d_center, const float *d_wh, const fl
 int yp_bbox_iou(const float *d_box1, const float *d_boxes2, int m, int row_stride,
                 float *d_out, void *stream);
 
+/* ---- ground-truth grid codec (the label-side data format of the path) ---------------- */
+
+/* Replaces create_true_box_grid, create_dataset.py:47-115, for a batch of images in one
+ * launch.  d_objects (total, 5) float64 rows [cx, cy, w, h, class] in original pixels, the
+ * objects of image b being rows d_object_offsets[b] .. d_object_offsets[b+1]-1 (B+1 int32
+ * offsets on the device).  Writes every element of d_grid (B, H, W, A, 5) float32
+ * [cx - col, cy - row, log(w / anchor_w), log(h / anchor_h), class] in grid units and of
+ * d_mask (B, H, W, A, 2) float32 (1, 1) at occupied slots, zeros elsewhere.  Arithmetic is
+ * binary64 with float32 anchors, as in the numpy code; when several objects of an image claim
+ * one (row, col, anchor) slot the last one in list order wins, as in the reference's loop.
+ * An object whose cell lies outside the grid is skipped (the reference raises IndexError or
+ * wraps a negative index).  anchors: HOST pointer to A (w, h) pairs in grid units. */
+int yp_encode_true_box_grid(const double *d_objects, const int32_t *d_object_offsets, int batch,
+                            int grid_h, int grid_w, int num_anchors, const float *anchors,
+                            int im_h, int im_w, float *d_grid, float *d_mask, void *stream);
+
+size_t yp_true_box_grid_workspace_bytes(int batch, int grid_h, int grid_w, int num_anchors);
+
+/* Replaces the grid decode of gather_grid_boxes, create_dataset.py:294-328, and the location
+ * extraction of get_metrics, train.py:332-338, for a batch of grids (B, H, W, A, 5):
+ *   d_out_index (out_cap, 4) int32 [image, row, col, anchor] of every slot with a non-zero
+ *               entry, in ascending lexicographic order (np.unique order)
+ *   d_out_boxes (out_cap, 4) float32 [cx, cy, w, h] in original pixels
+ *   d_out_class (out_cap)    float32 class value stored in the slot
+ *   d_out_count [1]          number of occupied slots (rows beyond out_cap are not stored) */
+int yp_decode_true_box_grid(const float *d_grid, int batch, int grid_h, int grid_w,
+                            int num_anchors, const float *anchors, int im_h, int im_w,
+                            int32_t *d_out_index, float *d_out_boxes, float *d_out_class,
+                            int64_t out_cap, int32_t *d_out_count, void *d_workspace,
+                            size_t workspace_bytes, void *stream);
+
 /* ---- measurement -------------------------------------------------------------------- */
 
 /* Per-kernel timing for benchmarks (no counterpart in the reference).  Between

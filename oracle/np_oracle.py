@@ -167,3 +167,90 @@ def n_write_results(rows, confidence, num_classes, nms_conf=0.4):
                 out.append([b, box[a, 0], box[a, 1], box[a, 2], box[a, 3],
                             p[a, 4], cscore[a], c])
     return np.array(out, f32).reshape(-1, 8)
+
+
+# ------------------------------------------------------ ground-truth grid codec (reference)
+
+def create_true_box_grid(y, anchors, grid_h=13, grid_w=13, im_h=1280, im_w=1920, true_vec_len=5):
+    """create_dataset.py:47-115, restated line by line (numpy float64 with float32 anchors, as
+    in the reference, where `y` is np.array(list of Python floats) and the anchors are the
+    float32 tensor of get_anchors()).  y: (n, 5) [cx, cy, w, h, class] in original pixels.
+    Objects whose cell lies outside the grid are skipped (the reference would raise an
+    IndexError for an index past the end and wrap a negative one)."""
+    A = len(anchors)
+    true_box_grid = np.zeros((grid_h, grid_w, A, true_vec_len), np.float32)          # :49
+    box_mask = np.zeros((grid_h, grid_w, A, 2), np.float32)                          # :50
+    mask_vec = np.ones((2), np.float32)
+    y = np.asarray(y, np.float64).reshape(-1, true_vec_len)
+    if y.shape[0] == 0:                                                              # :52
+        return true_box_grid, box_mask
+    orig_size = np.array([im_w, im_h])                                               # :56
+    center_boxes = y[:, :2] / orig_size                                              # :57
+    boxes_wh = y[:, 2:4] / orig_size                                                 # :59
+    conv_size = np.array([grid_w, grid_h])                                           # :61
+    center_boxes = center_boxes * conv_size                                          # :63
+    boxes_wh = boxes_wh * conv_size                                                  # :64
+    true_boxes = np.concatenate([center_boxes, boxes_wh, y[:, 4:]], axis=1)          # :66
+    anchors = np.asarray(anchors, np.float32)                                        # :67
+    for obj in range(y.shape[0]):                                                    # :70
+        best_iou = 0
+        best_anchor = 0
+        box = true_boxes[obj]
+        i = np.floor(box[1]).astype('int')                                           # :74 row
+        j = np.floor(box[0]).astype('int')                                           # :75 column
+        for k, anchor in enumerate(anchors):                                         # :79
+            box_max = box[2:4] / 2
+            box_min = -box_max
+            anchor_max = anchor / 2
+            anchor_min = -anchor_max
+            intersect_mins = np.maximum(box_min, anchor_min)
+            intersect_maxes = np.minimum(box_max, anchor_max)
+            intersect_wh = np.maximum(intersect_maxes - intersect_mins, 0)
+            intersect_area = intersect_wh[0] * intersect_wh[1]
+            box_area = box[2] * box[3]
+            anchor_area = anchor[0] * anchor[1]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                iou = intersect_area / (box_area + anchor_area - intersect_area)     # :94
+            if iou > best_iou:
+                best_iou = iou
+                best_anchor = k
+        if best_iou > 0 and 0 <= i < grid_h and 0 <= j < grid_w:                     # :100
+            with np.errstate(divide="ignore", invalid="ignore"):
+                adjusted_box = np.array(
+                    [box[0] - j, box[1] - i,
+                     np.log(box[2] / anchors[best_anchor][0]),
+                     np.log(box[3] / anchors[best_anchor][1]),
+                     box[4]], dtype=np.float32)                                      # :101-110
+            true_box_grid[i, j, best_anchor] = adjusted_box                          # :111
+            box_mask[i, j, best_anchor] = mask_vec                                   # :112
+    return true_box_grid, box_mask
+
+
+def true_box_locations(true_grid):
+    """The index extraction shared by gather_grid_boxes (create_dataset.py:294-304) and
+    get_metrics (train.py:332-338): unique leading indices of the non-zero entries, sorted.
+    true_grid (..., 5): returns (n, ndim-1) int64."""
+    g = np.asarray(true_grid)
+    idx = np.argwhere(g != 0)[:, :g.ndim - 1]
+    return np.unique(idx, axis=0) if len(idx) else np.zeros((0, g.ndim - 1), np.int64)
+
+
+def decode_true_box_grid(true_grid, anchors, im_h=1280, im_w=1920, exp=None):
+    """gather_grid_boxes, create_dataset.py:297-328: the boxes of one (H, W, A, 5) grid back in
+    original pixels, (n, 4) float32 [cx, cy, w, h] ordered by (row, col, anchor), plus their
+    locations.  `exp` lets the caller supply the bit-specified float32 exp."""
+    g = np.asarray(true_grid, f32)
+    H, W = g.shape[0], g.shape[1]
+    uniq = true_box_locations(g)                                                     # :297-304
+    if len(uniq) == 0:
+        return np.zeros((0, 4), f32), uniq
+    vec = g[uniq[:, 0], uniq[:, 1], uniq[:, 2]]                                      # :316
+    offs = np.stack([uniq[:, 1], uniq[:, 0]], 1).astype(f32)                         # :306-314 (x=j, y=i)
+    centre = vec[:, :2] + offs                                                       # :318
+    anc = np.asarray(anchors, f32)[uniq[:, 2]]                                       # :320
+    e = np.exp(vec[:, 2:4]) if exp is None else exp(vec[:, 2:4])                     # :321
+    wh = (e * anc).astype(f32)                                                       # :322
+    out = np.concatenate([centre, wh], 1).astype(f32)                                # :326
+    conv = np.array([W, H, W, H], f32)
+    orig = np.array([im_w, im_h, im_w, im_h], f32)
+    return ((out / conv) * orig).astype(f32), uniq                                   # :327-328

@@ -93,7 +93,48 @@ def golden_nms_edge_cases():
                         tf_scores=tf_scores, **out)
 
 
+def grid_codec_labels():
+    """Three images of labels [cx, cy, w, h, class] in 1920 x 1280 pixels: a random scene, an
+    empty image, and a scene with slot collisions (last object wins), a zero-area box, a centre
+    outside the frame and a centre on the last row / column boundary."""
+    rs = np.random.RandomState(303)
+    n = 24
+    scene = np.stack([rs.uniform(0, 1920, n), rs.uniform(0, 1280, n), rs.uniform(4, 900, n),
+                      rs.uniform(4, 700, n), rs.randint(0, 5, n).astype(np.float64)], 1)
+    edge = np.array([
+        [1000.0, 700.0, 300.0, 320.0, 1.0],     # slot (7, 6, anchor 1) ...
+        [1001.0, 701.0, 290.0, 310.0, 3.0],     # ... claimed again: this one must win
+        [1002.0, 702.0, 80.0, 70.0, 2.0],       # same cell, smaller anchor: separate slot
+        [500.0, 500.0, 0.0, 50.0, 4.0],         # zero area: best IoU 0, skipped
+        [2000.0, 100.0, 60.0, 60.0, 0.0],       # centre right of the frame: skipped
+        [-5.0, 100.0, 60.0, 60.0, 0.0],         # centre left of the frame: skipped
+        [1919.9, 1279.9, 1500.0, 1200.0, 4.0],  # last cell, largest anchor
+        [0.0, 0.0, 10.0, 10.0, 0.0],            # first cell, exactly on the corner
+    ])
+    return [scene, np.zeros((0, 5)), edge]
+
+
+def golden_grid_codec():
+    labels = grid_codec_labels()
+    grids, masks = zip(*[npo.create_true_box_grid(y, ANCHORS_R) for y in labels])
+    grids, masks = np.stack(grids), np.stack(masks)
+    assert masks[1].sum() == 0 and masks[2].sum() == 2 * 4
+    assert grids[2][7, 6, 1, 4] == 3.0            # the later object owns the contested slot
+    boxes, locs = [], []
+    for b, g in enumerate(grids):
+        bx, lc = npo.decode_true_box_grid(g, ANCHORS_R, exp=oracle.exp_spec)
+        alt, _ = npo.decode_true_box_grid(g, ANCHORS_R)
+        assert rel(bx, alt) < 1e-5
+        boxes.append(bx)
+        locs.append(np.concatenate([np.full((len(lc), 1), b, np.int64), lc], 1))
+    np.savez_compressed(
+        os.path.join(HERE, "grid_codec.npz"), labels=np.concatenate(labels),
+        label_offsets=np.cumsum([0] + [len(y) for y in labels]).astype(np.int32),
+        grid=grids, mask=masks, boxes=np.concatenate(boxes), locations=np.concatenate(locs))
+
+
 if __name__ == "__main__":
+    golden_grid_codec()
     golden_reference_mode()
     golden_yolov3_mode()
     golden_nms_edge_cases()
