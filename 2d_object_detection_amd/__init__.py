@@ -8,6 +8,8 @@ Drop-in call surface of lbadams2/2D_object_detection's hot path:
   ``bbox_iou`` and the fused ``YoloV3Post`` engine.
 * ``create_dataset`` -- the ground-truth grid codec ``create_true_box_grid`` /
   ``gather_grid_boxes`` (create_dataset.py:47-115, :278-329).
+* ``train`` -- ``loss_custom`` / ``loss_keras`` (one fused loss + gradient kernel),
+  ``get_metrics``, ``run_validation`` (train.py:110-353).
 * ``distributed`` -- batch sharding over the GPUs of a node and the variable-length
   all-gather of detection rows.
 
@@ -20,6 +22,7 @@ from . import synthetic  # noqa: F401
 from . import detect_net  # noqa: F401
 from . import util  # noqa: F401
 from . import create_dataset  # noqa: F401
+from . import train  # noqa: F401
 from . import distributed  # noqa: F401
 from .detect_net import DetectNet  # noqa: F401
 from .util import YoloV3Post, bbox_iou, predict_transform, write_results  # noqa: F401

@@ -27,6 +27,8 @@ EXPORTED_SYMBOLS = (
     "yp_rows_workspace_bytes", "yp_write_results", "yp_filter_boxes_reference",
     "yp_bbox_iou", "yp_profile_start", "yp_profile_stop",
     "yp_encode_true_box_grid", "yp_true_box_grid_workspace_bytes", "yp_decode_true_box_grid",
+    "yp_predict_transform_reference_backward",
+    "yp_loss_custom_reference_workspace_bytes", "yp_loss_custom_reference",
 )
 
 
@@ -117,6 +119,15 @@ def load():
     L.yp_decode_true_box_grid.restype = i32
     L.yp_decode_true_box_grid.argtypes = [vp, i32, i32, i32, i32, fp, i32, i32, vp, vp, vp, i64, vp,
                                           vp, sz, vp]
+    L.yp_predict_transform_reference_backward.restype = i32
+    L.yp_predict_transform_reference_backward.argtypes = [vp, i32, i32, i32, i32, i32, fp, vp, vp, vp,
+                                                          vp, vp, vp]
+    L.yp_loss_custom_reference_workspace_bytes.restype = sz
+    L.yp_loss_custom_reference_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    f32c = ctypes.c_float
+    L.yp_loss_custom_reference.restype = i32
+    L.yp_loss_custom_reference.argtypes = [vp, vp, i32, i32, i32, i32, i32, fp, f32c, f32c, f32c, f32c,
+                                           vp, vp, vp, sz, vp]
     _lib = L
     return L
 

@@ -78,6 +78,61 @@ def _alloc_outputs(B, device):
             torch.empty((B,), dtype=torch.int32, device=device))
 
 
+def _anchor_array(A):
+    return np.ascontiguousarray(np.asarray(params.YOLO_ANCHORS, dtype=np.float32).reshape(A, 2))
+
+
+def _decode_forward(pred, H, W, A, C):
+    B, dev = pred.shape[0], pred.device
+    center = torch.empty((B, H, W, A, 2), dtype=torch.float32, device=dev)
+    wh = torch.empty((B, H, W, A, 2), dtype=torch.float32, device=dev)
+    obj = torch.empty((B, H, W, A, 1), dtype=torch.float32, device=dev)
+    cls = torch.empty((B, H, W, A, C), dtype=torch.float32, device=dev)
+    if B == 0:
+        return center, wh, obj, cls
+    anc = _anchor_array(A)
+    with torch.cuda.device(dev):
+        rc = _lib.load().yp_predict_transform_reference(
+            pred.data_ptr(), B, H, W, A, C,
+            anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+            center.data_ptr(), wh.data_ptr(), obj.data_ptr(), cls.data_ptr(),
+            _lib.stream_ptr(dev))
+    _lib.check(rc, "yp_predict_transform_reference")
+    return center, wh, obj, cls
+
+
+class _PredictTransform(torch.autograd.Function):
+    """predict_transform with a hand-written backward kernel, so that the training losses
+    (train.py:123-197) can differentiate through it as tf.GradientTape does in the
+    reference (train.py:264-267)."""
+
+    @staticmethod
+    def forward(ctx, pred, H, W, A, C):
+        ctx.save_for_backward(pred)
+        ctx.geom = (H, W, A, C)
+        return _decode_forward(pred, H, W, A, C)
+
+    @staticmethod
+    def backward(ctx, g_center, g_wh, g_obj, g_cls):
+        (pred,) = ctx.saved_tensors
+        H, W, A, C = ctx.geom
+        B, dev = pred.shape[0], pred.device
+        grad = torch.empty_like(pred)
+        if B == 0:
+            return grad, None, None, None, None
+        gs = [None if g is None else _lib.as_f32(g, "upstream gradient")
+              for g in (g_center, g_wh, g_obj, g_cls)]
+        anc = _anchor_array(A)
+        with torch.cuda.device(dev):
+            rc = _lib.load().yp_predict_transform_reference_backward(
+                pred.data_ptr(), B, H, W, A, C,
+                anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                *[None if g is None else g.data_ptr() for g in gs],
+                grad.data_ptr(), _lib.stream_ptr(dev))
+        _lib.check(rc, "yp_predict_transform_reference_backward")
+        return grad, None, None, None, None
+
+
 class DetectNet():
     # survivors of the confidence filter per image for the most recent filter_boxes /
     # detect call (device tensor); diagnostic only
@@ -98,29 +153,17 @@ class DetectNet():
     def predict_transform(predictions):
         """Raw head -> (center_coords, wh_coords, obj_scores, class_probs)
         (detect_net.py:152-183).  Accepts anything reshapeable to
-        [-1, grid_height, grid_width, num_anchors, pred_vec_len]."""
+        [-1, grid_height, grid_width, num_anchors, pred_vec_len].  When the input requires
+        grad the four outputs are differentiable (backward runs a HIP kernel too)."""
         H, W = int(params.grid_height), int(params.grid_width)
         A, C = int(params.num_anchors), int(params.num_classes)
         V = int(params.pred_vec_len)
         if V != 5 + C:
             raise ValueError("params.pred_vec_len must equal 5 + params.num_classes")
         pred = _device_tensor(predictions, "predictions").reshape(-1, H, W, A, V)
-        B, dev = pred.shape[0], pred.device
-        center = torch.empty((B, H, W, A, 2), dtype=torch.float32, device=dev)
-        wh = torch.empty((B, H, W, A, 2), dtype=torch.float32, device=dev)
-        obj = torch.empty((B, H, W, A, 1), dtype=torch.float32, device=dev)
-        cls = torch.empty((B, H, W, A, C), dtype=torch.float32, device=dev)
-        if B == 0:
-            return center, wh, obj, cls
-        anc = np.ascontiguousarray(np.asarray(params.YOLO_ANCHORS, dtype=np.float32).reshape(A, 2))
-        with torch.cuda.device(dev):
-            rc = _lib.load().yp_predict_transform_reference(
-                pred.data_ptr(), B, H, W, A, C,
-                anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
-                center.data_ptr(), wh.data_ptr(), obj.data_ptr(), cls.data_ptr(),
-                _lib.stream_ptr(dev))
-        _lib.check(rc, "yp_predict_transform_reference")
-        return center, wh, obj, cls
+        if torch.is_grad_enabled() and pred.requires_grad:
+            return _PredictTransform.apply(pred, H, W, A, C)
+        return _decode_forward(pred, H, W, A, C)
 
     @staticmethod
     def filter_boxes(transformed_predictions):

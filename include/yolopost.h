@@ -198,6 +198,40 @@ int yp_decode_true_box_grid(const float *d_grid, int batch, int grid_h, int grid
                             int64_t out_cap, int32_t *d_out_count, void *d_workspace,
                             size_t workspace_bytes, void *stream);
 
+/* ---- backward of the reference decode (for the training losses) ---------------------- */
+
+/* Gradient of DetectNet.predict_transform, detect_net.py:152-183, with respect to its input,
+ * as loss_custom / loss_keras need it (train.py:123-197, :200-260; the reference gets it from
+ * tf.GradientTape, train.py:264-267).  d_grad_center (B,H,W,A,2), d_grad_wh (B,H,W,A,2),
+ * d_grad_obj (B,H,W,A,1), d_grad_cls (B,H,W,A,C) are the upstream gradients of the four
+ * outputs (any of them may be NULL = zero); d_grad_pred (B, H*W*A*(5+C)) receives the
+ * gradient of the raw head.  binary32 throughout; num_classes <= 64. */
+int yp_predict_transform_reference_backward(const float *d_pred, int batch, int grid_h,
+                                            int grid_w, int num_anchors, int num_classes,
+                                            const float *anchors, const float *d_grad_center,
+                                            const float *d_grad_wh, const float *d_grad_obj,
+                                            const float *d_grad_cls, float *d_grad_pred,
+                                            void *stream);
+
+size_t yp_loss_custom_reference_workspace_bytes(int batch, int grid_h, int grid_w,
+                                                int num_anchors);
+
+/* Replaces loss_custom, train.py:123-197 (and loss_keras, :200-270, the same arithmetic),
+ * from the raw head: value and gradient in one pass.
+ *   d_pred (B, H*W*A*(5+C)) raw head, d_true_grid (B,H,W,A,5) target grid
+ *   weights: params.coord_loss_weight, obj_loss_weight, noobj_loss_weight (params.py:11-13);
+ *   iou_thr: the 0.6 of train.py:167
+ *   d_loss  [4] float32: total (= 0.5 * sum of the next three), confidence, classification,
+ *           coordinates sums
+ *   d_grad_pred (B, H*W*A*(5+C)) d total / d d_pred, or NULL for the value only
+ * The detection indicator (IoU > iou_thr) is a constant for the gradient, as in TensorFlow. */
+int yp_loss_custom_reference(const float *d_pred, const float *d_true_grid, int batch,
+                             int grid_h, int grid_w, int num_anchors, int num_classes,
+                             const float *anchors, float coord_weight, float obj_weight,
+                             float noobj_weight, float iou_thr, float *d_loss,
+                             float *d_grad_pred, void *d_workspace, size_t workspace_bytes,
+                             void *stream);
+
 /* ---- measurement -------------------------------------------------------------------- */
 
 /* Per-kernel timing for benchmarks (no counterpart in the reference).  Between
