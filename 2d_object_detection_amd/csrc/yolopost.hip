@@ -22,6 +22,7 @@
 // YOLOv3 tutorial's predict_transform / write_results / bbox_iou in YP_MODE_YOLOV3; the
 // per-function citations are in include/yolopost.h.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "yolopost.h"
 #include "yp_math.h"
@@ -1390,25 +1391,41 @@ SegArgs make_seg_args(const Workspace &w, const YpParams *p, int spi, int tpi, i
     return s;
 }
 
-// Optional per-kernel timing: when enabled, every detect call records four HIP events
-// (before the front kernel and after each of its three launches) on the call's stream.
+// Optional per-kernel timing: while enabled, every kernel of a detect call is launched with
+// a start and a stop event of its own (hipExtLaunchKernelGGL), which carry the begin and end
+// time stamps of that dispatch; their difference is the kernel's execution time on the
+// device, without the host-side gaps a pair of hipEventRecord calls would include.
 struct ProfileState {
     bool on = false;
     int max_calls = 0;
     int calls = 0;
-    hipEvent_t *ev = nullptr;  // 4 per call
+    hipEvent_t *ev = nullptr;        // 6 per call: (start, stop) x (front, nms, gather)
+    unsigned char *launched = nullptr;  // per call: bit k set when kernel k was launched
 };
 ProfileState g_prof;
 
-inline void prof_mark(hipStream_t st, int k)
+inline bool prof_active() { return g_prof.on && g_prof.calls < g_prof.max_calls; }
+
+inline hipEvent_t prof_ev(int k, int end)
 {
-    if (g_prof.on && g_prof.calls < g_prof.max_calls) (void)hipEventRecord(g_prof.ev[4 * g_prof.calls + k], st);
+    g_prof.launched[g_prof.calls] |= (unsigned char)(1u << k);
+    return g_prof.ev[6 * g_prof.calls + 2 * k + end];
 }
 
 inline void prof_next()
 {
-    if (g_prof.on && g_prof.calls < g_prof.max_calls) ++g_prof.calls;
+    if (prof_active()) ++g_prof.calls;
 }
+
+// k: 0 front, 1 segment NMS, 2 gather.
+#define YP_LAUNCH(k, kernel, grid, block, lds, st, ...)                                          \
+    do {                                                                                         \
+        if (prof_active())                                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, prof_ev(k, 0), prof_ev(k, 1), 0, \
+                                  __VA_ARGS__);                                                  \
+        else                                                                                     \
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                       \
+    } while (0)
 
 // Segment NMS + final gather of the YOLOv3 path (shared by the heads and rows entries).
 int finish_v3(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, float *out_rows,
@@ -1419,8 +1436,7 @@ int finish_v3(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, f
     SegArgs s = make_seg_args(w, p, spi, tpi, ts, 1);
     s.max_out = p->max_out;
     if (stages & 2)
-        hipLaunchKernelGGL(k_segment_nms<YP_MODE_YOLOV3>, dim3(n_seg), dim3(kSegThreads), 0, st, s);
-    prof_mark(st, 2);
+        YP_LAUNCH(1, k_segment_nms<YP_MODE_YOLOV3>, dim3(n_seg), dim3(kSegThreads), 0, st, s);
     GatherArgs g = {};
     g.n_seg = n_seg;
     g.C = p->num_classes;
@@ -1438,8 +1454,7 @@ int finish_v3(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, f
     g.cap = cap;
     g.out_count = out_count;
     g.stats = stats;
-    if (stages & 4) hipLaunchKernelGGL(k_gather_rows, dim3(n_seg), dim3(256), 0, st, g);
-    prof_mark(st, 3);
+    if (stages & 4) YP_LAUNCH(2, k_gather_rows, dim3(n_seg), dim3(256), 0, st, g);
     prof_next();
     return (int)hipGetLastError();
 }
@@ -1455,9 +1470,7 @@ int finish_ref(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, 
     s.out_index = out_index;
     s.out_counts = out_counts;
     s.surv_counts = surv_counts;
-    hipLaunchKernelGGL(k_segment_nms<YP_MODE_REFERENCE>, dim3(p->batch), dim3(kSegThreads), 0, st, s);
-    prof_mark(st, 2);
-    prof_mark(st, 3);
+    YP_LAUNCH(1, k_segment_nms<YP_MODE_REFERENCE>, dim3(p->batch), dim3(kSegThreads), 0, st, s);
     prof_next();
     return (int)hipGetLastError();
 }
@@ -1560,23 +1573,20 @@ int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params, f
     const dim3 grid(ha.tpi, params->batch), block(kFrontCells * amax);
     float t_lo, t_hi;
     logit_band(params->conf_thr, &t_lo, &t_hi);
-    prof_mark(st, 0);
     ha.dbg = g_dbg_front;
     bool all_three = true;
     for (int i = 0; i < n_heads; ++i) all_three = all_three && heads[i].num_anchors == 3;
     if (params->reserved && !(params->reserved & 1)) {
         // benchmarking: the front stage is skipped (the workspace keeps the previous candidates)
     } else if (params->num_classes == 5 && all_three)
-        hipLaunchKernelGGL((k_front_heads_v3_wave<5, 3>), grid, dim3(64),
-                           (size_t)ts * (6 + 5) * sizeof(float), st, ha, cb, params->conf_thr, t_lo,
-                           t_hi);
+        YP_LAUNCH(0, (k_front_heads_v3_wave<5, 3>), grid, dim3(64),
+                  (size_t)ts * (6 + 5) * sizeof(float), st, ha, cb, params->conf_thr, t_lo, t_hi);
     else if (params->num_classes == 5)
-        hipLaunchKernelGGL(k_front_heads_v3<5>, grid, block, (size_t)ts * (6 + 5) * sizeof(float), st,
-                           ha, cb, params->conf_thr, t_lo, t_hi);
+        YP_LAUNCH(0, k_front_heads_v3<5>, grid, block, (size_t)ts * (6 + 5) * sizeof(float), st, ha, cb,
+                  params->conf_thr, t_lo, t_hi);
     else
-        hipLaunchKernelGGL(k_front_heads_v3<0>, grid, block, (size_t)ts * 6 * sizeof(float), st, ha,
-                           cb, params->conf_thr, t_lo, t_hi);
-    prof_mark(st, 1);
+        YP_LAUNCH(0, k_front_heads_v3<0>, grid, block, (size_t)ts * 6 * sizeof(float), st, ha, cb,
+                  params->conf_thr, t_lo, t_hi);
     return finish_v3(w, params, (int)spi, ha.tpi, ts, d_out_rows, out_cap, d_out_count, d_stats, st);
 }
 
@@ -1615,10 +1625,8 @@ int yp_write_results(const float *d_rows, int rows_per_image, const YpParams *pa
     carve(d_workspace, slots, tiles, (size_t)params->batch * params->num_classes, &w);
     CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile};
     hipStream_t st = (hipStream_t)stream;
-    prof_mark(st, 0);
-    hipLaunchKernelGGL(k_front_rows_v3, dim3(tpi, params->batch), dim3(kRowTile), 0, st, d_rows,
-                       rows_per_image, params->num_classes, cb, params->conf_thr);
-    prof_mark(st, 1);
+    YP_LAUNCH(0, k_front_rows_v3, dim3(tpi, params->batch), dim3(kRowTile), 0, st, d_rows,
+              rows_per_image, params->num_classes, cb, params->conf_thr);
     return finish_v3(w, params, (int)spi, tpi, kRowTile, d_out_rows, out_cap, d_out_count, d_stats,
                      st);
 }
@@ -1657,11 +1665,9 @@ int yp_detect_reference(const YpHead *head, const YpParams *params, float *d_out
     AnchorTable at = {};
     for (int i = 0; i < 2 * head->num_anchors; ++i) at.anc[i] = head->anchors[i];
     hipStream_t st = (hipStream_t)stream;
-    prof_mark(st, 0);
-    hipLaunchKernelGGL(k_front_grid_ref, dim3(tpi, params->batch), dim3(kRowTile), 0, st,
-                       head->data, head->grid_h, head->grid_w, head->num_anchors,
-                       params->num_classes, at, cb, params->conf_thr, params->im_h, params->im_w);
-    prof_mark(st, 1);
+    YP_LAUNCH(0, k_front_grid_ref, dim3(tpi, params->batch), dim3(kRowTile), 0, st, head->data,
+              head->grid_h, head->grid_w, head->num_anchors, params->num_classes, at, cb,
+              params->conf_thr, params->im_h, params->im_w);
     return finish_ref(w, params, (int)spi, tpi, kRowTile, d_out_boxes, d_out_scores, d_out_classes,
                       d_out_index, d_out_counts, d_surv_counts, st);
 }
@@ -1689,11 +1695,9 @@ int yp_filter_boxes_reference(const float *d_center, const float *d_wh, const fl
           (size_t)params->batch, &w);
     CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile};
     hipStream_t st = (hipStream_t)stream;
-    prof_mark(st, 0);
-    hipLaunchKernelGGL(k_front_split_ref, dim3(tpi, params->batch), dim3(kRowTile), 0, st, d_center,
-                       d_wh, d_obj, d_cls, rows_per_image, params->num_classes, cb,
-                       params->conf_thr, params->im_h, params->im_w);
-    prof_mark(st, 1);
+    YP_LAUNCH(0, k_front_split_ref, dim3(tpi, params->batch), dim3(kRowTile), 0, st, d_center, d_wh,
+              d_obj, d_cls, rows_per_image, params->num_classes, cb, params->conf_thr, params->im_h,
+              params->im_w);
     return finish_ref(w, params, (int)spi, tpi, kRowTile, d_out_boxes, d_out_scores, d_out_classes,
                       d_out_index, d_out_counts, d_surv_counts, st);
 }
@@ -1716,8 +1720,9 @@ int yp_debug_set_front_stamps(void *d_buf)
 int yp_profile_start(int max_calls)
 {
     if (max_calls <= 0 || max_calls > (1 << 16) || g_prof.on) return YP_ERR_ARG;
-    g_prof.ev = new hipEvent_t[4 * (size_t)max_calls];
-    for (int i = 0; i < 4 * max_calls; ++i) {
+    g_prof.ev = new hipEvent_t[6 * (size_t)max_calls];
+    g_prof.launched = new unsigned char[(size_t)max_calls]();
+    for (int i = 0; i < 6 * max_calls; ++i) {
         const hipError_t e = hipEventCreate(&g_prof.ev[i]);
         if (e != hipSuccess) return (int)e;
     }
@@ -1732,26 +1737,28 @@ int yp_profile_stop(double *front_ms, double *nms_ms, double *gather_ms, int *ca
     if (!g_prof.on || !front_ms || !nms_ms || !gather_ms || !calls) return YP_ERR_ARG;
     g_prof.on = false;
     double acc[3] = {0.0, 0.0, 0.0};
+    int cnt[3] = {0, 0, 0};
     int rc = YP_OK;
-    if (g_prof.calls > 0) {
-        const hipError_t e = hipEventSynchronize(g_prof.ev[4 * (g_prof.calls - 1) + 3]);
-        if (e != hipSuccess) rc = (int)e;
-    }
     for (int c = 0; c < g_prof.calls && rc == YP_OK; ++c)
         for (int k = 0; k < 3; ++k) {
+            if (!(g_prof.launched[c] & (1u << k))) continue;
             float ms = 0.f;
-            const hipError_t e = hipEventElapsedTime(&ms, g_prof.ev[4 * c + k], g_prof.ev[4 * c + k + 1]);
+            hipError_t e = hipEventSynchronize(g_prof.ev[6 * c + 2 * k + 1]);
+            if (e == hipSuccess)
+                e = hipEventElapsedTime(&ms, g_prof.ev[6 * c + 2 * k], g_prof.ev[6 * c + 2 * k + 1]);
             if (e != hipSuccess) { rc = (int)e; break; }
             acc[k] += ms;
+            ++cnt[k];
         }
     *calls = g_prof.calls;
-    const double n = g_prof.calls > 0 ? (double)g_prof.calls : 1.0;
-    *front_ms = acc[0] / n;
-    *nms_ms = acc[1] / n;
-    *gather_ms = acc[2] / n;
-    for (int i = 0; i < 4 * g_prof.max_calls; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+    *front_ms = cnt[0] ? acc[0] / cnt[0] : 0.0;
+    *nms_ms = cnt[1] ? acc[1] / cnt[1] : 0.0;
+    *gather_ms = cnt[2] ? acc[2] / cnt[2] : 0.0;
+    for (int i = 0; i < 6 * g_prof.max_calls; ++i) (void)hipEventDestroy(g_prof.ev[i]);
     delete[] g_prof.ev;
+    delete[] g_prof.launched;
     g_prof.ev = nullptr;
+    g_prof.launched = nullptr;
     g_prof.max_calls = g_prof.calls = 0;
     return rc;
 }

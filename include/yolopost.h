@@ -235,12 +235,13 @@ int yp_loss_custom_reference(const float *d_pred, const float *d_true_grid, int 
 /* ---- measurement -------------------------------------------------------------------- */
 
 /* Per-kernel timing for benchmarks (no counterpart in the reference).  Between
- * yp_profile_start and yp_profile_stop every yp_detect_*, yp_write_results and
- * yp_filter_boxes_reference call records HIP events around its launches, on the stream the
- * call uses (at most max_calls calls are recorded).  yp_profile_stop waits for the last
- * recorded event and returns the average milliseconds of the front (decode + filter +
- * compaction) kernel, the segment NMS kernel and the final gather kernel.  Not thread-safe;
- * intended for a single measuring thread. */
+ * yp_profile_start and yp_profile_stop every kernel of a yp_detect_*, yp_write_results or
+ * yp_filter_boxes_reference call is launched with a start and a stop HIP event of its own
+ * (hipExtLaunchKernelGGL), on the stream the call uses; at most max_calls calls are
+ * recorded.  yp_profile_stop waits for the recorded events and returns the average
+ * execution time in milliseconds of the front (decode + filter + compaction) kernel, the
+ * segment NMS kernel and the final gather kernel.  Not thread-safe; intended for a single
+ * measuring thread. */
 int yp_profile_start(int max_calls);
 int yp_profile_stop(double *front_ms, double *nms_ms, double *gather_ms, int *calls);
 

@@ -1,0 +1,118 @@
+"""Times the fused loss_custom kernel (value + gradient) and the decode backward kernel on one
+GPU, next to the same loss composed from torch ops on the GPU and the torch restatement on the
+CPU; prints one JSON line per kernel.
+
+    python tools/bench_train_kernels.py [--batch 4096] [--iters 50]
+
+Algorithmic bytes per (cell, anchor) slot: fused loss 4*(5+C) head + 20 target + 4*(5+C)
+gradient; decode backward 4*(5+C) head + 4*(5+C) upstream + 4*(5+C) gradient."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+yp = importlib.import_module("2d_object_detection_amd")
+H = W = 13
+A = C = 5
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--cpu-images", type=int, default=256)
+    a = ap.parse_args()
+    B = a.batch
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    pred = (torch.randn(B, H * W * A * (5 + C), generator=g) * 1.5).to(dev)
+    rs = np.random.RandomState(0)
+    n = 16
+    y = np.stack([rs.uniform(0, 1920, B * n), rs.uniform(0, 1280, B * n), rs.uniform(8, 1200, B * n),
+                  rs.uniform(8, 900, B * n), rs.randint(0, 5, B * n).astype(np.float64)], 1)
+    grid, _ = yp.create_dataset.encode_true_box_grids(
+        (torch.from_numpy(y).to(dev), torch.arange(0, (B + 1) * n, n, dtype=torch.int32, device=dev)))
+    ups = [torch.randn(B, H, W, A, k, device=dev) for k in (2, 2, 1, C)]
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / a.iters
+
+    def fused():
+        p = pred.detach().requires_grad_(True)
+        yp.train.loss_from_logits(p, grid).backward()
+
+    def backward_only():
+        p = pred.detach().requires_grad_(True)
+        torch.autograd.backward(yp.DetectNet.predict_transform(p), ups)
+
+    sys.path.insert(0, ROOT)
+    from oracle import torch_ref
+    anchors = np.asarray(yp.params.YOLO_ANCHORS)
+
+    def composed_gpu():
+        p = pred.detach().requires_grad_(True)
+        # the restatement's torch ops, executed on the GPU (dozens of elementwise kernels)
+        k = torch.arange(H * W, device=dev)
+        t = p.reshape(-1, H, W, A, 5 + C)
+        idx = torch.stack([k % H, k // H], 1).reshape(1, H, W, 1, 2).float()
+        dims = torch.tensor([H, W], dtype=torch.float32, device=dev).reshape(1, 1, 1, 1, 2)
+        center = (torch.sigmoid(t[..., 0:2]) + idx) / dims
+        obj = torch.sigmoid(t[..., 4:5])
+        anc = torch.as_tensor(anchors, dtype=torch.float32, device=dev).reshape(1, 1, 1, A, 2)
+        wh = torch.exp(t[..., 2:4]) * anc / dims
+        cls = torch.softmax(t[..., 5:], -1)
+        m = (grid[..., :1] != 0).float()
+        iwh = torch.clamp(torch.minimum(center + wh / 2, grid[..., 0:2] + grid[..., 2:4] / 2)
+                          - torch.maximum(center - wh / 2, grid[..., 0:2] - grid[..., 2:4] / 2), min=0)
+        inter = iwh[..., 0] * iwh[..., 1]
+        iou = (inter / (wh[..., 0] * wh[..., 1] + grid[..., 2] * grid[..., 3] - inter)).unsqueeze(-1)
+        det = (iou > 0.6).float()
+        onehot = torch.nn.functional.one_hot(grid[..., 4].long(), C).float()
+        loss = 0.5 * (((1 - det) * (1 - m) * obj ** 2 + 5 * m * (1 - obj) ** 2).sum()
+                      + (m * (onehot - cls) ** 2).sum()
+                      + (m * (grid[..., :4] - torch.cat([center, wh], -1)) ** 2).sum())
+        loss.backward()
+
+    fused_ms, back_ms, comp_ms = timed(fused), timed(backward_only), timed(composed_gpu)
+    slots = B * H * W * A
+    V = 5 + C
+    m = min(a.cpu_images, B)
+    pc, gc = pred[:m].cpu(), grid[:m].cpu()
+    t0 = time.perf_counter()
+    p = pc.clone().requires_grad_(True)
+    torch_ref.loss_custom(p, gc, H, W, A, C, anchors)[0].backward()
+    cpu_s = time.perf_counter() - t0
+    for name, ms, nbytes in (("loss_custom_value_and_grad", fused_ms, slots * (4 * V + 20 + 4 * V)),
+                             ("predict_transform_forward_backward", back_ms, slots * (4 * V * 3 + 4 * V * 2))):
+        print(json.dumps({
+            "metric": name + "_images_per_sec", "value": round(B / (ms * 1e-3), 1), "unit": "images/s",
+            "ms_per_call": round(ms, 5), "dtype": "f32",
+            "config": {"workload": "13x13x5 grid, C=5, %d images" % B},
+            "roofline": {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                         "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 8e12, 4),
+                         "algorithmic_bytes": nbytes,
+                         "note": "whole autograd round trip of the wrapper, not only the kernel"},
+            "same_loss_from_torch_ops_on_this_gpu_ms": round(comp_ms, 5),
+            "cpu_baseline": {"value": round(m / cpu_s, 1), "unit": "images/s",
+                             "cores": torch.get_num_threads(), "kind": "port",
+                             "sample": "%d images, torch restatement forward+backward" % m}}))
+
+
+if __name__ == "__main__":
+    main()
