@@ -653,24 +653,108 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l)
 // ------------------------------------------------------------------------------ segment NMS
 // LDS scratch of the chunk loop.
 struct ChunkShared {
-    float4 cbox[64];   // the chunk's 64 sorted rows
-    YpPrep kprep[64];  // kept rows of the chunk, prepared for IoU tests
-    u64 sup[64];       // row l: later rows of the chunk that row l suppresses
+    float4 cbox[64];   // the chunk's 64 sorted rows as stored
+    YpPrep cprep[64];  // the same rows prepared for IoU tests
+    YpPrep kprep[64];  // kept rows of the chunk, compacted
+    u64 sup[64];       // column c: alive earlier rows of the chunk that suppress row c
     u64 mask[2];       // [0] alive rows of the chunk, [1] kept rows of the chunk
 };
 
 // Greedy NMS over K sorted rows in chunks of 64.  sbox / removed / sslot are indexed by
 // sorted position and live either in LDS (small segments) or in the global workspace.
 // Returns the number of kept rows; emits each kept row through `emit(m, sorted_pos, box)`.
+#ifndef YP_COL_UNROLL
+#define YP_COL_UNROLL 4
+#endif
+constexpr int kColUnroll = YP_COL_UNROLL;
+
+// Staged suppression test of one row per lane (pi, valid where row_ok) against U columns that
+// are uniform over the wave: words[u] has bit l set when lane l's row suppresses column u.
+// The arithmetic is yp_suppress_pretest's, written stage by stage over the U independent
+// columns so that neighbouring instructions do not depend on each other; lanes the guard
+// bands leave undecided take the exact divide-and-compare.
+template <int MODE, int U>
+__device__ __forceinline__ void suppress_words(const YpPrep &pi, bool row_ok, const float4 *cj,
+                                               const float *aj, const YpThr &thr, u64 *words)
+{
+    const float plus1 = MODE == YP_MODE_YOLOV3 ? 1.0f : 0.0f;
+    float lo0[U], lo1[U], hi0[U], hi1[U], d0[U], d1[U], inter[U], uni[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) lo0[u] = vmax(pi.lo0, cj[u].x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) lo1[u] = vmax(pi.lo1, cj[u].y);
+#pragma unroll
+    for (int u = 0; u < U; ++u) hi0[u] = vmin(pi.hi0, cj[u].z);
+#pragma unroll
+    for (int u = 0; u < U; ++u) hi1[u] = vmin(pi.hi1, cj[u].w);
+#pragma unroll
+    for (int u = 0; u < U; ++u) d0[u] = hi0[u] - lo0[u] + plus1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) d1[u] = hi1[u] - lo1[u] + plus1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) d0[u] = vmax(d0[u], 0.0f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) d1[u] = vmax(d1[u], 0.0f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) inter[u] = d0[u] * d1[u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) uni[u] = pi.area + aj[u] - inter[u];
+    // verdicts as wave masks: every comparison lands in a scalar register pair, the logic on
+    // them is scalar, and the result already is the ballot
+    const u64 rowm = __ballot(row_ok);
+    const u64 fastm = thr.fast ? ~0ull : 0ull;
+    u64 und[U];
+    u64 any_und = 0ull;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const u64 yes = __ballot(inter[u] > thr.hi * uni[u]);
+        const u64 no = __ballot(inter[u] < thr.lo * uni[u]);
+        const u64 ok = __ballot(uni[u] > 1e-30f);
+        const u64 decided = fastm & ok & (yes | no);
+        u64 sup = decided & yes;
+        u64 open = ~decided;
+        if (MODE == YP_MODE_REFERENCE) {
+            const u64 deg = __ballot((pi.area <= 0.0f) | (aj[u] <= 0.0f));
+            sup = (sup & ~deg) | ((0.0f > thr.thr) ? deg : 0ull);
+            open &= ~deg;
+        }
+        words[u] = sup & rowm;
+        und[u] = open & rowm;
+        any_und |= und[u];
+    }
+    if (any_und != 0ull) {   // rare: some quotient sits within 2^-20 of the threshold
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (und[u] != 0ull) {
+                const YpPrep pj = {cj[u].x, cj[u].y, cj[u].z, cj[u].w, aj[u]};
+                const bool mine = (und[u] >> (threadIdx.x & 63)) & 1ull;
+                words[u] |= __ballot(mine && yp_suppresses_exact<MODE>(pi, pj, thr.thr));
+            }
+        }
+    }
+}
+
 template <int MODE, class Emit>
 __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *removed, int K,
                                           const YpThr thr, int max_out, ChunkShared &sh,
-                                          unsigned int &pairs, Emit emit)
+                                          float4 *colbox, float *colarea, int *colidx,
+                                          unsigned int &pairs, unsigned long long *dbgseg,
+                                          Emit emit)
 {
+#ifdef YP_STAMPS
+    unsigned long long acc[4] = {0, 0, 0, 0}, tprev = clock64();
+#define CHUNK_T(k)                                   \
+    do {                                             \
+        const unsigned long long tn = clock64();     \
+        acc[k] += tn - tprev;                        \
+        tprev = tn;                                  \
+    } while (0)
+#else
+#define CHUNK_T(k) do { } while (0)
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int nkept = 0;
     for (int r0 = 0; r0 < K && nkept < max_out; r0 += 64) {
-        u64 alive0 = 0ull;  // meaningful in wave 0
         if (wave == 0) {
             const int i = r0 + lane;
             float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -679,115 +763,147 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
                 bx = sbox[i];
                 alive = removed[i] == 0;
             }
+            const YpBox bl = {bx.x, bx.y, bx.z, bx.w};
             sh.cbox[lane] = bx;
-            alive0 = __ballot(alive);
+            sh.cprep[lane] = yp_prep<MODE>(bl);
+            const u64 alive0 = __ballot(alive);
             if (lane == 0) sh.mask[0] = alive0;
         }
         __syncthreads();
+        CHUNK_T(0);
         const u64 alive_mask = uniform64(sh.mask[0]);
         if (alive_mask == 0ull) {
             __syncthreads();
             continue;
         }
-        // 64x64 suppression bitmask tile: wave w builds rows w, w+8, ...; lane = column
+        // 64x64 tile of the chunk against itself: lanes hold the rows, wave w tests the
+        // columns 8w..8w+7 in one staged pass; sup[c] = alive rows before c that suppress c
         {
-            const float4 cj = sh.cbox[lane];
-            const YpBox bj = {cj.x, cj.y, cj.z, cj.w};
-            const YpPrep pj = yp_prep<MODE>(bj);
-            const bool col_alive = (alive_mask >> lane) & 1ull;
-            for (int l = wave; l < 64; l += 2 * kSegWaves) {
-                const int l2 = l + kSegWaves;
-                const bool a1 = (alive_mask >> l) & 1ull, a2 = (alive_mask >> l2) & 1ull;
-                u64 m1 = 0ull, m2 = 0ull;
-                if (a1 || a2) {
-                    const float4 c1 = sh.cbox[l], c2 = sh.cbox[l2];
-                    const YpBox b1 = {c1.x, c1.y, c1.z, c1.w}, b2 = {c2.x, c2.y, c2.z, c2.w};
-                    const YpPrep p1 = yp_prep<MODE>(b1), p2 = yp_prep<MODE>(b2);
-                    const bool t1 = a1 && (lane > l) && col_alive;
-                    const bool t2 = a2 && (lane > l2) && col_alive;
-                    const bool s1 = t1 && yp_suppresses<MODE>(p1, pj, thr);
-                    const bool s2 = t2 && yp_suppresses<MODE>(p2, pj, thr);
-                    m1 = __ballot(s1);
-                    m2 = __ballot(s2);
-                    pairs += (t1 ? 1u : 0u) + (t2 ? 1u : 0u);
+            static_assert(kSegWaves * 8 == 64, "eight columns per wave cover the tile");
+            const YpPrep pi = sh.cprep[lane];
+            const bool row_ok = (alive_mask >> lane) & 1ull;
+            u64 mine = 0ull;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float4 cj[4];
+                float aj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const YpPrep pc = sh.cprep[(wave << 3) + 4 * half + u];
+                    cj[u] = make_float4(pc.lo0, pc.lo1, pc.hi0, pc.hi1);
+                    aj[u] = pc.area;
                 }
-                if (lane == 0) {
-                    sh.sup[l] = m1;
-                    sh.sup[l2] = m2;
-                }
+                u64 words[4];
+                suppress_words<MODE, 4>(pi, row_ok, cj, aj, thr, words);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) mine = lane == 4 * half + u ? words[u] : mine;
+            }
+            if (lane < 8) {
+                const int c = (wave << 3) + lane;
+                sh.sup[c] = mine & lanes_below(c);
+            }
+            if (tid == 0) {
+                const unsigned int na = (unsigned int)__popcll(alive_mask);
+                pairs += na * (na - 1u) / 2u;
             }
         }
         __syncthreads();
-        // wavefront sweep: lane l holds row l's mask; walk the alive rows in order
+        CHUNK_T(1);
+        // greedy keep set of the chunk as the fixed point of
+        // keep[c] = alive[c] && no kept earlier row of the chunk suppresses c  (wave 0, ballots)
         if (wave == 0) {
-            const u64 mysup = sh.sup[lane];
-            u64 alive = alive_mask, keptm = 0ull;
-            int nk = nkept;
-            while (alive != 0ull && nk < max_out) {
-                const int l = __ffsll((long long)alive) - 1;
-                const u64 bit = 1ull << l;
-                keptm |= bit;
-                ++nk;
-                alive &= ~(readlane64(mysup, l) | bit);
+            const u64 mycol = sh.sup[lane];
+            const bool alive = (alive_mask >> lane) & 1ull;
+            u64 keptm = alive_mask;
+            for (int it = 0; it < 66; ++it) {
+                const u64 nk = __ballot(alive && (mycol & keptm) == 0ull);
+                if (nk == keptm) break;
+                keptm = nk;
             }
+            const int room = max_out - nkept;
+            if (__popcll(keptm) > room)
+                keptm = __ballot(((keptm >> lane) & 1ull) && __popcll(keptm & lanes_below(lane)) < room);
             if (lane == 0) sh.mask[1] = keptm;
             if ((keptm >> lane) & 1ull) {
                 const int pos = __popcll(keptm & lanes_below(lane));
-                const float4 cb4 = sh.cbox[lane];
-                const YpBox bl = {cb4.x, cb4.y, cb4.z, cb4.w};
-                sh.kprep[pos] = yp_prep<MODE>(bl);
-                emit(nkept + pos, r0 + lane, cb4);
+                sh.kprep[pos] = sh.cprep[lane];
+                emit(nkept + pos, r0 + lane, sh.cbox[lane]);
             }
         }
         __syncthreads();
+        CHUNK_T(2);
         const int nkc = __popcll(uniform64(sh.mask[1]));
         nkept += nkc;
         if (nkept >= max_out) break;
-        // column pass: the later columns are tested against the chunk's kept rows.  When
-        // there are fewer columns than threads, G = 2^k lanes share one column (each takes
-        // every G-th kept row) and combine their verdicts with a ballot.
+        // column pass: the later columns are tested against the chunk's kept rows.  Lanes
+        // hold the kept rows (at most 64, one per lane); every wave stages 64 columns at a
+        // time in its own LDS slice (prepared corners + area, removed columns skipped) and
+        // walks the live ones kColUnroll at a time: one pass of the staged arithmetic tests a
+        // column against all kept rows at once, the verdict is a ballot, and the columns to
+        // drop are collected in a wave-uniform mask that the lanes store at the end.
         const int ncols = K - (r0 + 64);
         if (nkc > 0 && ncols > 0) {
-            int G = 1;
-            while (G < 64 && ncols * (G << 1) <= kSegThreads) G <<= 1;
-            const int g = tid & (G - 1);
-            const int cpp = kSegThreads / G;  // columns per pass
-            const u64 gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane & ~(G - 1));
-            for (int j0 = r0 + 64; j0 < K; j0 += cpp) {
-                const int j = j0 + tid / G;
-                bool sup = false;
-                const bool live = (j < K) && removed[j] == 0;
-                if (live) {
-                    const float4 cj = sbox[j];
-                    const YpBox bj = {cj.x, cj.y, cj.z, cj.w};
+            const bool row_ok = lane < nkc;
+            const YpPrep pi = sh.kprep[row_ok ? lane : 0];
+            float4 *wbox = colbox + (wave << 6);
+            float *warea = colarea + (wave << 6);
+            int *wcol = colidx + (wave << 6);
+            for (int j0 = r0 + 64 + (wave << 6); j0 < K; j0 += kSegThreads) {
+                const int j = j0 + lane;
+                const bool live = j < K && removed[j] == 0;
+                const u64 lm = __ballot(live);
+                const int nlive = __popcll(lm);
+                if (live) {   // live columns are staged densely, in order
+                    const int pos = __popcll(lm & lanes_below(lane));
+                    const float4 raw = sbox[j];
+                    const YpBox bj = {raw.x, raw.y, raw.z, raw.w};
                     const YpPrep pj = yp_prep<MODE>(bj);
-                    int q = g;
-                    for (; q + G < nkc && !sup; q += 2 * G) {
-                        const bool s0 = yp_suppresses<MODE>(sh.kprep[q], pj, thr);
-                        const bool s1 = yp_suppresses<MODE>(sh.kprep[q + G], pj, thr);
-                        pairs += 2u;
-                        sup = s0 || s1;
-                    }
-                    if (!sup && q < nkc) {
-                        ++pairs;
-                        sup = yp_suppresses<MODE>(sh.kprep[q], pj, thr);
-                    }
+                    wbox[pos] = make_float4(pj.lo0, pj.lo1, pj.hi0, pj.hi1);
+                    warea[pos] = pj.area;
+                    wcol[pos] = j;
                 }
-                if (G == 1) {
-                    if (sup) removed[j] = 1;
-                } else {
-                    const u64 bal = __ballot(sup);
-                    if (g == 0 && live && (bal & gmask) != 0ull) removed[j] = 1;
+                if (lane == 0) pairs += (unsigned int)(nkc * nlive);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                u64 drop = 0ull;
+                for (int c = 0; c < nlive; c += kColUnroll) {
+                    float4 cj[kColUnroll];
+                    float aj[kColUnroll];
+#pragma unroll
+                    for (int u = 0; u < kColUnroll; ++u) {   // (slots past nlive hold stale boxes)
+                        cj[u] = wbox[c + u];
+                        aj[u] = warea[c + u];
+                    }
+                    u64 words[kColUnroll];
+                    suppress_words<MODE, kColUnroll>(pi, row_ok, cj, aj, thr, words);
+#pragma unroll
+                    for (int u = 0; u < kColUnroll; ++u)
+                        drop |= (words[u] != 0ull ? 1ull : 0ull) << (c + u);
                 }
+                if (((drop >> lane) & 1ull) && lane < nlive) removed[wcol[lane]] = 1;
+                __builtin_amdgcn_wave_barrier();   // the slice is reused by the next batch
             }
         }
         __syncthreads();
+        CHUNK_T(3);
     }
+#ifdef YP_STAMPS
+    if (threadIdx.x == 0 && dbgseg)
+        for (int k = 0; k < 4; ++k) dbgseg[24 + k] = acc[k];
+#endif
     return nkept;
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(2, 4)))
+#ifndef YP_PAIR_UNROLL
+#define YP_PAIR_UNROLL 4
+#endif
+#ifndef YP_NMS_MIN_WAVES
+#define YP_NMS_MIN_WAVES 6
+#define YP_NMS_MAX_WAVES 6
+#endif
+__global__ __launch_bounds__(kSegThreads)
+__attribute__((amdgpu_waves_per_eu(YP_NMS_MIN_WAVES, YP_NMS_MAX_WAVES)))
 void k_segment_nms(SegArgs s)
 {
     // s_raw: sort keys of segments above kSmallCap (bitonic sort, up to kSortCap keys); for
@@ -958,7 +1074,7 @@ void k_segment_nms(SegArgs s)
         // columns so that neighbouring instructions do not depend on each other.  Same
         // arithmetic and guard bands as yp_suppress_pretest (one-instruction min/max);
         // undecided lanes take the exact divide-and-compare.
-        constexpr int kPairUnroll = 8;
+        constexpr int kPairUnroll = YP_PAIR_UNROLL;
         const int wu = __builtin_amdgcn_readfirstlane(wave);
         for (int w = 0; w < nwords; ++w) {
             const int i = (w << 6) + lane;
@@ -1101,7 +1217,17 @@ void k_segment_nms(SegArgs s)
         __syncthreads();
         STAMP(4);
         sslot_final = gslot;
-        nkept = nms_chunks<MODE>(gbox, grem, K, yp_make_thr(s.thr), max_out, s_chunk, pairs,
+        // the sort keys are no longer needed: s_raw becomes the column staging area
+        static_assert(kSegThreads * 24 + 8 * 16 <= kRawBytes, "column staging must fit the key buffer");
+        nkept = nms_chunks<MODE>(gbox, grem, K, yp_make_thr(s.thr), max_out, s_chunk,
+                                 reinterpret_cast<float4 *>(s_raw),
+                                 reinterpret_cast<float *>(s_raw + kSegThreads * 16),
+                                 reinterpret_cast<int *>(s_raw + kSegThreads * 20), pairs,
+#ifdef YP_STAMPS
+                                 s.dbg ? s.dbg + (size_t)blockIdx.x * 32 : nullptr,
+#else
+                                 nullptr,
+#endif
                                  [&](int m, int sp, const float4 &bx) { emit_kept(gslot, m, sp, bx); });
     }
     (void)sslot_final;

@@ -54,6 +54,11 @@ print("shader clock during the NMS phase: %.0f MHz (cycles / wall time, median o
       % float(np.median(dc / dt) / 1e6))
 
 print("candidates per segment: mean %.0f max %d" % (eng.segment_stats()[0].mean(), eng.segment_stats()[0].max()))
+if eng.segment_stats()[0].max() > 512:
+    ph = raw[:, 24:28] / 2400.0    # shader cycles -> us at 2.4 GHz
+    print("chunk loop of the large-segment path, mean us per segment: load %.1f, tile %.1f, "
+          "sweep %.1f, column pass %.1f" % tuple(ph.mean(0)))
+    sys.exit(0)
 it = raw[:, 24:32]
 print("pair-matrix iteration starts of wave 0 (shader cycles after the phase start, median):")
 print([int(np.median(it[:, k] - raw[:, 16 + 4])) for k in range(8) if np.median(it[:, k]) > 0],
