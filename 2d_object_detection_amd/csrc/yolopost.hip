@@ -34,7 +34,8 @@ typedef unsigned long long u64;
 constexpr int kRowTile = 256;     // rows per tile in the row-mapped front kernels
 constexpr int kFrontGroups = 2;   // 64-cell groups per tile of the YOLOv3 heads front kernel
 constexpr int kFrontCells = 64 * kFrontGroups;
-constexpr int kSegThreads = 512;  // threads per NMS workgroup
+constexpr int kStageWin = 128;    // survivors staged per round by the single-wave front kernel
+constexpr int kSegThreads = 512;  // threads per NMS workgroup (the kernel is only validated for 512)
 constexpr int kSegWaves = kSegThreads / 64;
 constexpr int kSortCap = 2048;    // largest segment sorted in LDS
 constexpr int kSmallCap = 512;    // segments up to this size use the all-pairs LDS bitmask path
@@ -89,11 +90,13 @@ struct SegArgs {
     const int *cand_cls;
     const int *tile_count;
     int *tile_prefix;        // [B*tpi] exclusive prefix of tile_count inside an image
-    u64 *gkeys;              // [2*B*spi] sort area for segments larger than kSortCap
+    u64 *gkeys;              // [2*B*spi] sort area for segments larger than kSortCap, then their
+                             // boxes in x order
     float4 *sbox;            // [B*spi] boxes in sorted order, per segment region
     int *sslot;              // [B*spi] slot ids in sorted order
     unsigned char *removed;  // [B*spi] suppression flags in sorted order
     int *kept_slot;          // [B*spi] slot ids of kept rows, per segment region
+    int *xidx;               // [B*spi] large segments: sorted positions in x order, -1 = struck
     int *seg_kept;           // [n_seg]
     int *seg_cand;           // [n_seg]
     int *seg_region;         // [n_seg] region start inside the image
@@ -422,48 +425,56 @@ __global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBu
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int a = 0; a < NA; ++a) rank += __popcll(bal[c][a] & below);
+    // the staging area holds kStageWin survivors; a tile with more (rare) takes several rounds
+    for (int base = 0; base < total; base += kStageWin) {
+        int rk = rank - base;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < 2; ++c) {
 #pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            if (pass[c][a]) {
-                float *st = s_stage + rank * kStride;
+            for (int a = 0; a < NA; ++a) {
+                if (pass[c][a] && rk >= 0 && rk < kStageWin) {
+                    float *st = s_stage + rk * kStride;
 #pragma unroll
-                for (int v = 0; v < 5; ++v) st[v] = t[c][a][v];
-                reinterpret_cast<int *>(st)[5] = (a << 24) | (cell + c);
+                    for (int v = 0; v < 5; ++v) st[v] = t[c][a][v];
+                    reinterpret_cast<int *>(st)[5] = (a << 24) | (cell + c);
 #pragma unroll
-                for (int j = 0; j < CS; ++j) st[6 + j] = t[c][a][5 + j];
+                    for (int j = 0; j < CS; ++j) st[6 + j] = t[c][a][5 + j];
+                }
+                rk += pass[c][a] ? 1 : 0;
             }
-            rank += pass[c][a] ? 1 : 0;
         }
-    }
-    // single wave: its LDS writes above reach the LDS before its reads below (in-order queue);
-    // the wavefront-scope fence only stops the compiler from moving them across each other
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+        // single wave: its LDS writes above reach the LDS before its reads below (in-order
+        // queue); the wavefront-scope fence only stops the compiler from moving them across
+        // each other
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #ifdef YP_STAMPS
-    if (lane == 0 && ha.dbg) ha.dbg[dbg_blk * 4 + 2] = wall_clock64();
+        if (lane == 0 && ha.dbg && base == 0) ha.dbg[dbg_blk * 4 + 2] = wall_clock64();
 #endif
-    for (int r = lane; r < total; r += 64) {
-        const float *st = s_stage + r * kStride;
-        const int packed = reinterpret_cast<const int *>(st)[5];
-        const int sa = packed >> 24, scell = packed & 0xffffff;
-        const int row = scell / g.gw, col = scell - row * g.gw;
-        const float obj = yp_sigmoid(st[4]);
-        const float cx = (yp_sigmoid(st[0]) + (float)col) * g.sx;
-        const float cy = (yp_sigmoid(st[1]) + (float)row) * g.sy;
-        const float w = (yp_exp(st[2]) * g.anc[2 * sa + 0]) * g.sx;
-        const float hgt = (yp_exp(st[3]) * g.anc[2 * sa + 1]) * g.sy;
-        float best = yp_sigmoid(st[6]);
-        int bi = 0;
+        const int end = total < base + kStageWin ? total : base + kStageWin;
+        for (int r = base + lane; r < end; r += 64) {
+            const float *st = s_stage + (r - base) * kStride;
+            const int packed = reinterpret_cast<const int *>(st)[5];
+            const int sa = packed >> 24, scell = packed & 0xffffff;
+            const int row = scell / g.gw, col = scell - row * g.gw;
+            const float obj = yp_sigmoid(st[4]);
+            const float cx = (yp_sigmoid(st[0]) + (float)col) * g.sx;
+            const float cy = (yp_sigmoid(st[1]) + (float)row) * g.sy;
+            const float w = (yp_exp(st[2]) * g.anc[2 * sa + 0]) * g.sx;
+            const float hgt = (yp_exp(st[3]) * g.anc[2 * sa + 1]) * g.sy;
+            float best = yp_sigmoid(st[6]);
+            int bi = 0;
 #pragma unroll
-        for (int j = 1; j < CS; ++j) {
-            const float sc = yp_sigmoid(st[6 + j]);
-            if (sc > best) { best = sc; bi = j; }
+            for (int j = 1; j < CS; ++j) {
+                const float sc = yp_sigmoid(st[6 + j]);
+                if (sc > best) { best = sc; bi = j; }
+            }
+            const float hw = w * 0.5f, hh = hgt * 0.5f;
+            YpBox bx = {cx - hw, cy - hh, cx + hw, cy + hh};
+            store_cand(cb, ((size_t)b * cb.tpi + tile) * cb.ts + r, bx, obj + 0.0f, best, bi);
         }
-        const float hw = w * 0.5f, hh = hgt * 0.5f;
-        YpBox bx = {cx - hw, cy - hh, cx + hw, cy + hh};
-        store_cand(cb, ((size_t)b * cb.tpi + tile) * cb.ts + r, bx, obj + 0.0f, best, bi);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the next round overwrites the staging area
     }
     if (lane == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = total;
 #ifdef YP_STAMPS
@@ -737,7 +748,7 @@ __device__ __forceinline__ void suppress_words(const YpPrep &pi, bool row_ok, co
 template <int MODE, class Emit>
 __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *removed, int K,
                                           const YpThr thr, int max_out, ChunkShared &sh,
-                                          float4 *colbox, float *colarea, int *colidx,
+                                          const float4 *xraw, int *xidx, bool prune,
                                           unsigned int &pairs, unsigned long long *dbgseg,
                                           Emit emit)
 {
@@ -779,27 +790,28 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
         // 64x64 tile of the chunk against itself: lanes hold the rows, wave w tests the
         // columns 8w..8w+7 in one staged pass; sup[c] = alive rows before c that suppress c
         {
-            static_assert(kSegWaves * 8 == 64, "eight columns per wave cover the tile");
+            constexpr int kTileCols = 64 / kSegWaves;   // columns of the tile per wave
+            static_assert(kTileCols % 4 == 0 && kTileCols * kSegWaves == 64, "whole passes of 4");
             const YpPrep pi = sh.cprep[lane];
             const bool row_ok = (alive_mask >> lane) & 1ull;
             u64 mine = 0ull;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int part = 0; part < kTileCols / 4; ++part) {
                 float4 cj[4];
                 float aj[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const YpPrep pc = sh.cprep[(wave << 3) + 4 * half + u];
+                    const YpPrep pc = sh.cprep[wave * kTileCols + 4 * part + u];
                     cj[u] = make_float4(pc.lo0, pc.lo1, pc.hi0, pc.hi1);
                     aj[u] = pc.area;
                 }
                 u64 words[4];
                 suppress_words<MODE, 4>(pi, row_ok, cj, aj, thr, words);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) mine = lane == 4 * half + u ? words[u] : mine;
+                for (int u = 0; u < 4; ++u) mine = lane == 4 * part + u ? words[u] : mine;
             }
-            if (lane < 8) {
-                const int c = (wave << 3) + lane;
+            if (lane < kTileCols) {
+                const int c = wave * kTileCols + lane;
                 sh.sup[c] = mine & lanes_below(c);
             }
             if (tid == 0) {
@@ -835,53 +847,80 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
         const int nkc = __popcll(uniform64(sh.mask[1]));
         nkept += nkc;
         if (nkept >= max_out) break;
-        // column pass: the later columns are tested against the chunk's kept rows.  Lanes
-        // hold the kept rows (at most 64, one per lane); every wave stages 64 columns at a
-        // time in its own LDS slice (prepared corners + area, removed columns skipped) and
-        // walks the live ones kColUnroll at a time: one pass of the staged arithmetic tests a
-        // column against all kept rows at once, the verdict is a ballot, and the columns to
-        // drop are collected in a wave-uniform mask that the lanes store at the end.
-        const int ncols = K - (r0 + 64);
-        if (nkc > 0 && ncols > 0) {
-            const bool row_ok = lane < nkc;
-            const YpPrep pi = sh.kprep[row_ok ? lane : 0];
-            float4 *wbox = colbox + (wave << 6);
-            float *warea = colarea + (wave << 6);
-            int *wcol = colidx + (wave << 6);
-            for (int j0 = r0 + 64 + (wave << 6); j0 < K; j0 += kSegThreads) {
-                const int j = j0 + lane;
-                const bool live = j < K && removed[j] == 0;
-                const u64 lm = __ballot(live);
-                const int nlive = __popcll(lm);
-                if (live) {   // live columns are staged densely, in order
-                    const int pos = __popcll(lm & lanes_below(lane));
-                    const float4 raw = sbox[j];
-                    const YpBox bj = {raw.x, raw.y, raw.z, raw.w};
+        // column pass: the later columns are tested against the chunk's kept rows.  Lanes hold
+        // columns, 64 neighbours of the x-ordered list at a time, so a batch covers a narrow
+        // band of the image; only the kept rows whose extent along the pruning axis reaches
+        // that band (2 px of slack: more than any rounding of the IoU arithmetic) are walked,
+        // four at a time through the staged test with the row values uniform over the wave.
+        // A kept row outside the band has intersection 0 with every column of the batch, which
+        // `prune` (threshold inside the guard-band range, all areas positive) makes a "does not
+        // suppress" verdict; without `prune` every kept row is walked.  Each list position is
+        // owned by one lane of one wave for the whole loop: a removed column is struck from the
+        // list (xidx = -1) by its owner and flagged in `removed` for the chunk loader.
+        if (nkc > 0 && r0 + 64 < K) {
+            const YpPrep kr = sh.kprep[lane < nkc ? lane : 0];
+            const float rlo = MODE == YP_MODE_YOLOV3 ? kr.lo0 : kr.lo1;
+            const float rhi = MODE == YP_MODE_YOLOV3 ? kr.hi0 : kr.hi1;
+            const int nb = (K + 63) >> 6;
+            int bt = wave;
+            int idx_c = -1;
+            float4 raw_c = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bt < nb && (bt << 6) + lane < K) {
+                idx_c = xidx[(bt << 6) + lane];
+                raw_c = xraw[(bt << 6) + lane];
+            }
+            for (; bt < nb; bt += kSegWaves) {
+                const int p = (bt << 6) + lane;
+                const int pn = p + (kSegWaves << 6);   // this lane's position in the next batch
+                int idx_n = -1;
+                float4 raw_n = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pn < K) {
+                    idx_n = xidx[pn];
+                    raw_n = xraw[pn];
+                }
+                const bool live = idx_c >= r0 + 64;
+                const u64 livem = __ballot(live);
+                if (livem != 0ull) {
+                    const YpBox bj = {raw_c.x, raw_c.y, raw_c.z, raw_c.w};
                     const YpPrep pj = yp_prep<MODE>(bj);
-                    wbox[pos] = make_float4(pj.lo0, pj.lo1, pj.hi0, pj.hi1);
-                    warea[pos] = pj.area;
-                    wcol[pos] = j;
-                }
-                if (lane == 0) pairs += (unsigned int)(nkc * nlive);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                u64 drop = 0ull;
-                for (int c = 0; c < nlive; c += kColUnroll) {
-                    float4 cj[kColUnroll];
-                    float aj[kColUnroll];
+                    const float clo = MODE == YP_MODE_YOLOV3 ? pj.lo0 : pj.lo1;
+                    const float chi = MODE == YP_MODE_YOLOV3 ? pj.hi0 : pj.hi1;
+                    float bl = live ? clo : __builtin_inff();
+                    float bh = live ? chi : -__builtin_inff();
 #pragma unroll
-                    for (int u = 0; u < kColUnroll; ++u) {   // (slots past nlive hold stale boxes)
-                        cj[u] = wbox[c + u];
-                        aj[u] = warea[c + u];
+                    for (int off = 32; off > 0; off >>= 1) {
+                        bl = vmin(bl, __shfl_xor(bl, off, 64));
+                        bh = vmax(bh, __shfl_xor(bh, off, 64));
                     }
-                    u64 words[kColUnroll];
-                    suppress_words<MODE, kColUnroll>(pi, row_ok, cj, aj, thr, words);
+                    // (negated comparisons: a NaN keeps the row)
+                    u64 todo = __ballot(lane < nkc &&
+                                        (!prune || (!(rhi + 2.0f < bl) && !(rlo - 2.0f > bh))));
+                    if (lane == 0) pairs += (unsigned int)(__popcll(livem) * __popcll(todo));
+                    u64 drop = 0ull;
+                    while (todo != 0ull) {
+                        int q[kColUnroll];
+                        float4 cj[kColUnroll];
+                        float aj[kColUnroll];
 #pragma unroll
-                    for (int u = 0; u < kColUnroll; ++u)
-                        drop |= (words[u] != 0ull ? 1ull : 0ull) << (c + u);
+                        for (int u = 0; u < kColUnroll; ++u) {
+                            q[u] = todo != 0ull ? __ffsll((long long)todo) - 1 : -1;
+                            todo &= todo - 1ull;   // 0 stays 0
+                            const YpPrep pr = sh.kprep[q[u] < 0 ? 0 : q[u]];
+                            cj[u] = make_float4(pr.lo0, pr.lo1, pr.hi0, pr.hi1);
+                            aj[u] = pr.area;
+                        }
+                        u64 words[kColUnroll];
+                        suppress_words<MODE, kColUnroll>(pj, live, cj, aj, thr, words);
+#pragma unroll
+                        for (int u = 0; u < kColUnroll; ++u) drop |= q[u] >= 0 ? words[u] : 0ull;
+                    }
+                    if ((drop >> lane) & 1ull) {   // (only live lanes can be set)
+                        removed[idx_c] = 1;
+                        xidx[p] = -1;
+                    }
                 }
-                if (((drop >> lane) & 1ull) && lane < nlive) removed[wcol[lane]] = 1;
-                __builtin_amdgcn_wave_barrier();   // the slice is reused by the next batch
+                idx_c = idx_n;
+                raw_c = raw_n;
             }
         }
         __syncthreads();
@@ -1217,12 +1256,94 @@ void k_segment_nms(SegArgs s)
         __syncthreads();
         STAMP(4);
         sslot_final = gslot;
-        // the sort keys are no longer needed: s_raw becomes the column staging area
-        static_assert(kSegThreads * 24 + 8 * 16 <= kRawBytes, "column staging must fit the key buffer");
-        nkept = nms_chunks<MODE>(gbox, grem, K, yp_make_thr(s.thr), max_out, s_chunk,
-                                 reinterpret_cast<float4 *>(s_raw),
-                                 reinterpret_cast<float *>(s_raw + kSegThreads * 16),
-                                 reinterpret_cast<int *>(s_raw + kSegThreads * 20), pairs,
+        // ---- x-order of the candidates: counting sort by the box centre along the pruning
+        // axis into 256 buckets (LDS histogram; the order inside a bucket is whatever the
+        // atomics give, which only changes which lane owns which column, never a verdict).
+        // The sort keys are no longer needed, so their global region becomes the x-ordered
+        // copy of the boxes and s_raw the histogram.
+        constexpr int kXB = 256;
+        static_assert(kXB <= kSegThreads && (2 * kXB + 4 * kSegWaves) * 4 <= kRawBytes, "histogram fits");
+        int *s_hist = reinterpret_cast<int *>(s_raw);
+        int *s_cur = s_hist + kXB;
+        float *s_red = reinterpret_cast<float *>(s_cur + kXB);       // [2 * kSegWaves] min, max
+        int *s_pos = reinterpret_cast<int *>(s_red + 2 * kSegWaves); // [kSegWaves] all areas > 0
+        float4 *xraw = reinterpret_cast<float4 *>(gk + 2 * (size_t)region);
+        int *xidx = s.xidx + reg;
+        auto axis_key = [&](const float4 &raw, bool &positive) {
+            const YpBox bx = {raw.x, raw.y, raw.z, raw.w};
+            const YpPrep pp = yp_prep<MODE>(bx);
+            positive = pp.area > 0.0f;
+            return MODE == YP_MODE_YOLOV3 ? pp.lo0 + pp.hi0 : pp.lo1 + pp.hi1;
+        };
+        {
+            float kmin = __builtin_inff(), kmax = -__builtin_inff();
+            bool allpos = true;
+            for (int i = tid; i < K; i += kSegThreads) {
+                bool positive;
+                const float key = axis_key(gbox[i], positive);
+                kmin = vmin(kmin, key);
+                kmax = vmax(kmax, key);
+                allpos = allpos && positive;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                kmin = vmin(kmin, __shfl_xor(kmin, off, 64));
+                kmax = vmax(kmax, __shfl_xor(kmax, off, 64));
+            }
+            const u64 posm = __ballot(allpos);
+            if (lane == 0) {
+                s_red[wave] = kmin;
+                s_red[kSegWaves + wave] = kmax;
+                s_pos[wave] = posm == ~0ull ? 1 : 0;
+            }
+            if (tid < kXB) s_hist[tid] = 0;
+        }
+        __syncthreads();
+        float kmin = s_red[0], kmax = s_red[kSegWaves];
+        bool allpos = s_pos[0] != 0;
+#pragma unroll
+        for (int w = 1; w < kSegWaves; ++w) {
+            kmin = vmin(kmin, s_red[w]);
+            kmax = vmax(kmax, s_red[kSegWaves + w]);
+            allpos = allpos && s_pos[w] != 0;
+        }
+        const float range = kmax - kmin;
+        const float scale = (range > 0.0f && range < 3.0e38f) ? (float)kXB / range : 0.0f;
+        auto bucket = [&](float key) {
+            float t = (key - kmin) * scale;
+            t = t > 0.0f ? t : 0.0f;                       // also turns a NaN into bucket 0
+            t = t < (float)(kXB - 1) ? t : (float)(kXB - 1);
+            return (int)t;
+        };
+        for (int i = tid; i < K; i += kSegThreads) {
+            bool positive;
+            atomicAdd(&s_hist[bucket(axis_key(gbox[i], positive))], 1);
+        }
+        __syncthreads();
+        if (tid < kXB) {   // exclusive scan of the 256 counts by the first four waves
+            const int v = s_hist[tid];
+            const int incl = wave_inclusive_scan(v, lane);
+            if (lane == 63) s_scan[wave] = incl;
+            s_cur[tid] = incl - v;
+        }
+        __syncthreads();
+        if (tid < kXB) {
+            int woff = 0;
+            for (int w = 0; w < kXB / 64; ++w) woff += w < wave ? s_scan[w] : 0;
+            s_cur[tid] += woff;
+        }
+        __syncthreads();
+        for (int i = tid; i < K; i += kSegThreads) {
+            bool positive;
+            const float4 raw = gbox[i];
+            const int pos = atomicAdd(&s_cur[bucket(axis_key(raw, positive))], 1);
+            xidx[pos] = i;
+            xraw[pos] = raw;
+        }
+        __syncthreads();
+        const YpThr thr = yp_make_thr(s.thr);
+        const bool prune = thr.fast && (MODE == YP_MODE_REFERENCE || allpos);
+        nkept = nms_chunks<MODE>(gbox, grem, K, thr, max_out, s_chunk, xraw, xidx, prune, pairs,
 #ifdef YP_STAMPS
                                  s.dbg ? s.dbg + (size_t)blockIdx.x * 32 : nullptr,
 #else
@@ -1373,6 +1494,7 @@ struct Workspace {
     int *sslot;
     unsigned char *removed;
     int *kept_slot;
+    int *xidx;
     int *seg_kept;
     int *seg_cand;
     int *seg_region;
@@ -1405,6 +1527,7 @@ size_t carve(void *base_v, size_t slots, size_t tiles, size_t n_seg, Workspace *
     off = carve_one(base, off, slots, &w->sslot);
     off = carve_one(base, off, slots, &w->removed);
     off = carve_one(base, off, slots, &w->kept_slot);
+    off = carve_one(base, off, slots, &w->xidx);
     off = carve_one(base, off, n_seg, &w->seg_kept);
     off = carve_one(base, off, n_seg, &w->seg_cand);
     off = carve_one(base, off, n_seg, &w->seg_region);
@@ -1509,6 +1632,7 @@ SegArgs make_seg_args(const Workspace &w, const YpParams *p, int spi, int tpi, i
     s.sslot = w.sslot;
     s.removed = w.removed;
     s.kept_slot = w.kept_slot;
+    s.xidx = w.xidx;
     s.seg_kept = w.seg_kept;
     s.seg_cand = w.seg_cand;
     s.seg_region = w.seg_region;
@@ -1706,7 +1830,7 @@ int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params, f
         // benchmarking: the front stage is skipped (the workspace keeps the previous candidates)
     } else if (params->num_classes == 5 && all_three)
         YP_LAUNCH(0, (k_front_heads_v3_wave<5, 3>), grid, dim3(64),
-                  (size_t)ts * (6 + 5) * sizeof(float), st, ha, cb, params->conf_thr, t_lo, t_hi);
+                  (size_t)kStageWin * (6 + 5) * sizeof(float), st, ha, cb, params->conf_thr, t_lo, t_hi);
     else if (params->num_classes == 5)
         YP_LAUNCH(0, k_front_heads_v3<5>, grid, block, (size_t)ts * (6 + 5) * sizeof(float), st, ha, cb,
                   params->conf_thr, t_lo, t_hi);
