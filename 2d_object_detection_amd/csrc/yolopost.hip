@@ -96,7 +96,7 @@ struct SegArgs {
     int *sslot;              // [B*spi] slot ids in sorted order
     unsigned char *removed;  // [B*spi] suppression flags in sorted order
     int *kept_slot;          // [B*spi] slot ids of kept rows, per segment region
-    int *xidx;               // [B*spi] large segments: sorted positions in x order, -1 = struck
+    int *xidx;               // [B*spi] large segments: sorted positions of the live columns in x order
     int *seg_kept;           // [n_seg]
     int *seg_cand;           // [n_seg]
     int *seg_region;         // [n_seg] region start inside the image
@@ -662,13 +662,21 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l)
 }
 
 // ------------------------------------------------------------------------------ segment NMS
+// Kept rows of up to kPend chunks wait in LDS before one pass over the later columns applies
+// them all ("flush"); until then every new chunk is first tested against the waiting rows.
+#ifndef YP_PEND
+#define YP_PEND 2
+#endif
+constexpr int kPend = YP_PEND;
+
 // LDS scratch of the chunk loop.
 struct ChunkShared {
-    float4 cbox[64];   // the chunk's 64 sorted rows as stored
-    YpPrep cprep[64];  // the same rows prepared for IoU tests
-    YpPrep kprep[64];  // kept rows of the chunk, compacted
-    u64 sup[64];       // column c: alive earlier rows of the chunk that suppress row c
-    u64 mask[2];       // [0] alive rows of the chunk, [1] kept rows of the chunk
+    float4 cbox[64];            // the chunk's 64 sorted rows as stored
+    YpPrep cprep[64];           // the same rows prepared for IoU tests
+    YpPrep kprep[kPend * 64];   // kept rows not yet applied to the later columns, compacted
+    u64 sup[64];                // column c: alive earlier rows of the chunk that suppress row c
+    u64 mask[2];                // [0] alive rows of the chunk, [1] kept rows of the chunk
+    unsigned long long pend_sup;  // rows of the chunk suppressed by a pending kept row
 };
 
 // Greedy NMS over K sorted rows in chunks of 64.  sbox / removed / sslot are indexed by
@@ -748,7 +756,7 @@ __device__ __forceinline__ void suppress_words(const YpPrep &pi, bool row_ok, co
 template <int MODE, class Emit>
 __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *removed, int K,
                                           const YpThr thr, int max_out, ChunkShared &sh,
-                                          const float4 *xraw, int *xidx, bool prune,
+                                          float4 *xraw, int *xidx, bool prune,
                                           unsigned int &pairs, unsigned long long *dbgseg,
                                           Emit emit)
 {
@@ -765,6 +773,11 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int nkept = 0;
+    int npend = 0;   // kept rows waiting in sh.kprep (uniform over the workgroup)
+    // the x-ordered list is split into one contiguous part per wave (whole batches of 64)
+    const int per_wave = (((K + 63) >> 6) + kSegWaves - 1) / kSegWaves * 64;
+    const int wbeg = wave * per_wave < K ? wave * per_wave : K;
+    int wlen = (K - wbeg) < per_wave ? (K - wbeg) : per_wave;
     for (int r0 = 0; r0 < K && nkept < max_out; r0 += 64) {
         if (wave == 0) {
             const int i = r0 + lane;
@@ -778,103 +791,136 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
             sh.cbox[lane] = bx;
             sh.cprep[lane] = yp_prep<MODE>(bl);
             const u64 alive0 = __ballot(alive);
-            if (lane == 0) sh.mask[0] = alive0;
+            if (lane == 0) {
+                sh.mask[0] = alive0;
+                sh.pend_sup = 0ull;
+            }
         }
         __syncthreads();
         CHUNK_T(0);
-        const u64 alive_mask = uniform64(sh.mask[0]);
-        if (alive_mask == 0ull) {
-            __syncthreads();
-            continue;
-        }
-        // 64x64 tile of the chunk against itself: lanes hold the rows, wave w tests the
-        // columns 8w..8w+7 in one staged pass; sup[c] = alive rows before c that suppress c
-        {
-            constexpr int kTileCols = 64 / kSegWaves;   // columns of the tile per wave
-            static_assert(kTileCols % 4 == 0 && kTileCols * kSegWaves == 64, "whole passes of 4");
-            const YpPrep pi = sh.cprep[lane];
-            const bool row_ok = (alive_mask >> lane) & 1ull;
-            u64 mine = 0ull;
-#pragma unroll
-            for (int part = 0; part < kTileCols / 4; ++part) {
+        u64 alive_mask = uniform64(sh.mask[0]);
+        // the waiting kept rows against the chunk: lanes hold the chunk's rows, every wave
+        // walks its share of the waiting rows four at a time, verdicts are OR-ed in LDS
+        if (npend > 0 && alive_mask != 0ull) {
+            const YpPrep pc = sh.cprep[lane];
+            const bool col_ok = (alive_mask >> lane) & 1ull;
+            u64 acc = 0ull;
+            int tested = 0;
+            for (int q0 = wave * 4; q0 < npend; q0 += kSegWaves * 4) {
+                tested += npend - q0 < 4 ? npend - q0 : 4;
                 float4 cj[4];
                 float aj[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const YpPrep pc = sh.cprep[wave * kTileCols + 4 * part + u];
-                    cj[u] = make_float4(pc.lo0, pc.lo1, pc.hi0, pc.hi1);
-                    aj[u] = pc.area;
+                    const YpPrep pr = sh.kprep[q0 + u < npend ? q0 + u : q0];
+                    cj[u] = make_float4(pr.lo0, pr.lo1, pr.hi0, pr.hi1);
+                    aj[u] = pr.area;
                 }
                 u64 words[4];
-                suppress_words<MODE, 4>(pi, row_ok, cj, aj, thr, words);
+                suppress_words<MODE, 4>(pc, col_ok, cj, aj, thr, words);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) mine = lane == 4 * part + u ? words[u] : mine;
+                for (int u = 0; u < 4; ++u) acc |= q0 + u < npend ? words[u] : 0ull;
             }
-            if (lane < kTileCols) {
-                const int c = wave * kTileCols + lane;
-                sh.sup[c] = mine & lanes_below(c);
+            if (lane == 0) {
+                if (acc != 0ull) atomicOr(&sh.pend_sup, (unsigned long long)acc);
+                pairs += (unsigned int)(__popcll(alive_mask) * tested);
             }
-            if (tid == 0) {
-                const unsigned int na = (unsigned int)__popcll(alive_mask);
-                pairs += na * (na - 1u) / 2u;
-            }
+            __syncthreads();
+            alive_mask &= ~uniform64(sh.pend_sup);
         }
-        __syncthreads();
-        CHUNK_T(1);
-        // greedy keep set of the chunk as the fixed point of
-        // keep[c] = alive[c] && no kept earlier row of the chunk suppresses c  (wave 0, ballots)
-        if (wave == 0) {
-            const u64 mycol = sh.sup[lane];
-            const bool alive = (alive_mask >> lane) & 1ull;
-            u64 keptm = alive_mask;
-            for (int it = 0; it < 66; ++it) {
-                const u64 nk = __ballot(alive && (mycol & keptm) == 0ull);
-                if (nk == keptm) break;
-                keptm = nk;
+        int nkc = 0;
+        if (alive_mask != 0ull) {
+            // 64x64 tile of the chunk against itself: lanes hold the rows, wave w tests the
+            // columns 8w..8w+7 in staged passes; sup[c] = alive rows before c that suppress c
+            {
+                constexpr int kTileCols = 64 / kSegWaves;   // columns of the tile per wave
+                static_assert(kTileCols % 4 == 0 && kTileCols * kSegWaves == 64, "whole passes of 4");
+                const YpPrep pi = sh.cprep[lane];
+                const bool row_ok = (alive_mask >> lane) & 1ull;
+                u64 mine = 0ull;
+#pragma unroll
+                for (int part = 0; part < kTileCols / 4; ++part) {
+                    float4 cj[4];
+                    float aj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const YpPrep pc = sh.cprep[wave * kTileCols + 4 * part + u];
+                        cj[u] = make_float4(pc.lo0, pc.lo1, pc.hi0, pc.hi1);
+                        aj[u] = pc.area;
+                    }
+                    u64 words[4];
+                    suppress_words<MODE, 4>(pi, row_ok, cj, aj, thr, words);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) mine = lane == 4 * part + u ? words[u] : mine;
+                }
+                if (lane < kTileCols) {
+                    const int c = wave * kTileCols + lane;
+                    sh.sup[c] = mine & lanes_below(c);
+                }
+                if (tid == 0) {
+                    const unsigned int na = (unsigned int)__popcll(alive_mask);
+                    pairs += na * (na - 1u) / 2u;
+                }
             }
-            const int room = max_out - nkept;
-            if (__popcll(keptm) > room)
-                keptm = __ballot(((keptm >> lane) & 1ull) && __popcll(keptm & lanes_below(lane)) < room);
-            if (lane == 0) sh.mask[1] = keptm;
-            if ((keptm >> lane) & 1ull) {
-                const int pos = __popcll(keptm & lanes_below(lane));
-                sh.kprep[pos] = sh.cprep[lane];
-                emit(nkept + pos, r0 + lane, sh.cbox[lane]);
+            __syncthreads();
+            CHUNK_T(1);
+            // greedy keep set of the chunk as the fixed point of
+            // keep[c] = alive[c] && no kept earlier row of the chunk suppresses c  (wave 0)
+            if (wave == 0) {
+                const u64 mycol = sh.sup[lane];
+                const bool alive = (alive_mask >> lane) & 1ull;
+                u64 keptm = alive_mask;
+                for (int it = 0; it < 66; ++it) {
+                    const u64 nk = __ballot(alive && (mycol & keptm) == 0ull);
+                    if (nk == keptm) break;
+                    keptm = nk;
+                }
+                const int room = max_out - nkept;
+                if (__popcll(keptm) > room)
+                    keptm = __ballot(((keptm >> lane) & 1ull) && __popcll(keptm & lanes_below(lane)) < room);
+                if (lane == 0) sh.mask[1] = keptm;
+                if ((keptm >> lane) & 1ull) {
+                    const int pos = __popcll(keptm & lanes_below(lane));
+                    sh.kprep[npend + pos] = sh.cprep[lane];
+                    emit(nkept + pos, r0 + lane, sh.cbox[lane]);
+                }
             }
+            __syncthreads();
+            CHUNK_T(2);
+            nkc = __popcll(uniform64(sh.mask[1]));
+            nkept += nkc;
+            npend += nkc;
+            if (nkept >= max_out) break;
         }
-        __syncthreads();
-        CHUNK_T(2);
-        const int nkc = __popcll(uniform64(sh.mask[1]));
-        nkept += nkc;
-        if (nkept >= max_out) break;
-        // column pass: the later columns are tested against the chunk's kept rows.  Lanes hold
-        // columns, 64 neighbours of the x-ordered list at a time, so a batch covers a narrow
-        // band of the image; only the kept rows whose extent along the pruning axis reaches
-        // that band (2 px of slack: more than any rounding of the IoU arithmetic) are walked,
-        // four at a time through the staged test with the row values uniform over the wave.
-        // A kept row outside the band has intersection 0 with every column of the batch, which
-        // `prune` (threshold inside the guard-band range, all areas positive) makes a "does not
-        // suppress" verdict; without `prune` every kept row is walked.  Each list position is
-        // owned by one lane of one wave for the whole loop: a removed column is struck from the
-        // list (xidx = -1) by its owner and flagged in `removed` for the chunk loader.
-        if (nkc > 0 && r0 + 64 < K) {
-            const YpPrep kr = sh.kprep[lane < nkc ? lane : 0];
-            const float rlo = MODE == YP_MODE_YOLOV3 ? kr.lo0 : kr.lo1;
-            const float rhi = MODE == YP_MODE_YOLOV3 ? kr.hi0 : kr.hi1;
-            const int nb = (K + 63) >> 6;
-            int bt = wave;
+        // flush: the later columns are tested against the waiting kept rows once there is no
+        // room for another chunk's worth of them.  Lanes hold columns, 64 neighbours of the
+        // x-ordered list at a time, so a batch covers a narrow band of the image; only the
+        // kept rows whose extent along the pruning axis reaches that band (2 px of slack:
+        // more than any rounding of the IoU arithmetic) are walked, four at a time through
+        // the staged test with the row values uniform over the wave.  A kept row outside the
+        // band has intersection 0 with every column of the batch, which `prune` (threshold
+        // inside the guard-band range, all areas positive) makes a "does not suppress"
+        // verdict; without `prune` every waiting row is walked.  Every wave owns one contiguous
+        // part of the list for the whole loop; a removed column is flagged in `removed` for
+        // the chunk loader and leaves the list.
+        if (npend > (kPend - 1) * 64 && r0 + 64 < K) {
+            const int nrw = (npend + 63) >> 6;   // words of waiting rows
+            // this wave's part of the list is [wbeg, wbeg + wlen); survivors are written back
+            // densely from wbeg on (never ahead of the read position), so the next flush finds
+            // full batches and no struck or already processed columns
+            int out = wbeg;
+            const int wend = wbeg + wlen;
             int idx_c = -1;
             float4 raw_c = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bt < nb && (bt << 6) + lane < K) {
-                idx_c = xidx[(bt << 6) + lane];
-                raw_c = xraw[(bt << 6) + lane];
+            if (wbeg + lane < wend) {
+                idx_c = xidx[wbeg + lane];
+                raw_c = xraw[wbeg + lane];
             }
-            for (; bt < nb; bt += kSegWaves) {
-                const int p = (bt << 6) + lane;
-                const int pn = p + (kSegWaves << 6);   // this lane's position in the next batch
+            for (int pos = wbeg; pos < wend; pos += 64) {
+                const int pn = pos + 64 + lane;   // this lane's position in the next batch
                 int idx_n = -1;
                 float4 raw_n = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pn < K) {
+                if (pn < wend) {
                     idx_n = xidx[pn];
                     raw_n = xraw[pn];
                 }
@@ -892,36 +938,49 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
                         bl = vmin(bl, __shfl_xor(bl, off, 64));
                         bh = vmax(bh, __shfl_xor(bh, off, 64));
                     }
-                    // (negated comparisons: a NaN keeps the row)
-                    u64 todo = __ballot(lane < nkc &&
-                                        (!prune || (!(rhi + 2.0f < bl) && !(rlo - 2.0f > bh))));
-                    if (lane == 0) pairs += (unsigned int)(__popcll(livem) * __popcll(todo));
                     u64 drop = 0ull;
-                    while (todo != 0ull) {
-                        int q[kColUnroll];
-                        float4 cj[kColUnroll];
-                        float aj[kColUnroll];
+                    for (int rw = 0; rw < nrw; ++rw) {
+                        const int rq = (rw << 6) + lane;
+                        const YpPrep kr = sh.kprep[rq < npend ? rq : 0];
+                        const float rlo = MODE == YP_MODE_YOLOV3 ? kr.lo0 : kr.lo1;
+                        const float rhi = MODE == YP_MODE_YOLOV3 ? kr.hi0 : kr.hi1;
+                        // (negated comparisons: a NaN keeps the row)
+                        u64 todo = __ballot(rq < npend &&
+                                            (!prune || (!(rhi + 2.0f < bl) && !(rlo - 2.0f > bh))));
+                        if (lane == 0) pairs += (unsigned int)(__popcll(livem) * __popcll(todo));
+                        while (todo != 0ull) {
+                            int q[kColUnroll];
+                            float4 cj[kColUnroll];
+                            float aj[kColUnroll];
 #pragma unroll
-                        for (int u = 0; u < kColUnroll; ++u) {
-                            q[u] = todo != 0ull ? __ffsll((long long)todo) - 1 : -1;
-                            todo &= todo - 1ull;   // 0 stays 0
-                            const YpPrep pr = sh.kprep[q[u] < 0 ? 0 : q[u]];
-                            cj[u] = make_float4(pr.lo0, pr.lo1, pr.hi0, pr.hi1);
-                            aj[u] = pr.area;
+                            for (int u = 0; u < kColUnroll; ++u) {
+                                q[u] = todo != 0ull ? __ffsll((long long)todo) - 1 : -1;
+                                todo &= todo - 1ull;   // 0 stays 0
+                                const YpPrep pr = sh.kprep[(rw << 6) + (q[u] < 0 ? 0 : q[u])];
+                                cj[u] = make_float4(pr.lo0, pr.lo1, pr.hi0, pr.hi1);
+                                aj[u] = pr.area;
+                            }
+                            u64 words[kColUnroll];
+                            suppress_words<MODE, kColUnroll>(pj, live, cj, aj, thr, words);
+#pragma unroll
+                            for (int u = 0; u < kColUnroll; ++u) drop |= q[u] >= 0 ? words[u] : 0ull;
                         }
-                        u64 words[kColUnroll];
-                        suppress_words<MODE, kColUnroll>(pj, live, cj, aj, thr, words);
-#pragma unroll
-                        for (int u = 0; u < kColUnroll; ++u) drop |= q[u] >= 0 ? words[u] : 0ull;
                     }
-                    if ((drop >> lane) & 1ull) {   // (only live lanes can be set)
-                        removed[idx_c] = 1;
-                        xidx[p] = -1;
+                    const bool dropped = (drop >> lane) & 1ull;   // (only live lanes can be set)
+                    if (dropped) removed[idx_c] = 1;
+                    const u64 stay = livem & ~drop;
+                    if (live && !dropped) {
+                        const int dst = out + __popcll(stay & lanes_below(lane));
+                        xidx[dst] = idx_c;
+                        xraw[dst] = raw_c;
                     }
+                    out += __popcll(stay);
                 }
                 idx_c = idx_n;
                 raw_c = raw_n;
             }
+            wlen = out - wbeg;
+            npend = 0;
         }
         __syncthreads();
         CHUNK_T(3);
