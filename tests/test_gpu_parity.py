@@ -165,6 +165,68 @@ def test_v3_ties_thresholds_and_degenerate_boxes(pkg, dev):
         assert np.array_equal(npo.n_write_results(pred, 0.5, C, nms), want), nms
 
 
+def big_segment_rows(n, seed, span=1900.0, degenerate=False, offset=0.0):
+    """One image, one dominant class, n rows that all pass the filter: a segment far above
+    the 512-row all-pairs path, with clusters so that suppression chains exist."""
+    rs = np.random.RandomState(seed)
+    C = 2
+    centres = rs.uniform(0, span, (n // 6 + 1, 2))
+    pick = rs.randint(0, len(centres), n)
+    cx = centres[pick, 0] + rs.normal(0, 6, n) + offset
+    cy = centres[pick, 1] * 0.6 + rs.normal(0, 6, n)
+    w = rs.choice([12.0, 30.0, 70.0, 260.0], n, p=[0.5, 0.3, 0.15, 0.05]) * np.exp(rs.normal(0, 0.3, n))
+    h = w * np.exp(rs.normal(0, 0.3, n))
+    obj = rs.uniform(0.55, 0.999, n)
+    obj[rs.randint(0, n, n // 20)] = 0.75              # ties in the sort key
+    rows = np.zeros((1, n, 5 + C), np.float32)
+    rows[0, :, 0], rows[0, :, 1], rows[0, :, 2], rows[0, :, 3], rows[0, :, 4] = cx, cy, w, h, obj
+    rows[0, :, 5] = 0.9
+    rows[0, :, 6] = 0.1
+    rows[0, rs.randint(0, n, n // 10), 5:] = [0.1, 0.9]   # a smaller second class
+    if degenerate:
+        k = rs.randint(0, n, n // 25)
+        rows[0, k, 2] = -1.0                           # x2 - x1 + 1 == 0: zero "+1" area
+        k = rs.randint(0, n, n // 25)
+        rows[0, k, 2:4] = [-9.0, -5.0]                 # inverted corners, positive area product
+        k = rs.randint(0, n, n // 40)
+        rows[0, k, 2:4] = 0.0
+    return rows, C
+
+
+@pytest.mark.parametrize("n,seed,nms,degenerate,offset", [
+    (1500, 1, 0.4, False, 0.0),       # pruned flushes, several waves' list parts
+    (3000, 2, 0.45, False, 0.0),      # beyond the LDS sort: global keys, many flushes
+    (1400, 3, 0.4, True, 0.0),        # non-positive areas switch the pruning off
+    (1300, 4, 0.0, False, 0.0),       # threshold 0: nothing may be skipped, everything suppresses
+    (1300, 5, 1.0, False, 0.0),       # threshold 1: only identical boxes suppress
+    (1600, 6, 0.4, False, 3.0e7),     # coordinates where a float's spacing exceeds 2 px
+    (700, 7, 0.3, False, 0.0),        # just above the all-pairs path
+])
+def test_v3_large_segments_match_oracle(pkg, dev, n, seed, nms, degenerate, offset):
+    util = pkg.util
+    rows, C = big_segment_rows(n, seed, degenerate=degenerate, offset=offset)
+    want, surv, _ = oracle.n_write_results(rows, 0.5, C, nms)
+    assert surv.max() > 512
+    got = util.write_results(torch.from_numpy(rows).to(dev), 0.5, C, nms)
+    got = np.zeros((0, 8), np.float32) if isinstance(got, int) else got.cpu().numpy()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.array_equal(got, want)
+
+
+def test_ref_large_segment_all_survive(pkg, dev, monkeypatch):
+    """Reference mode with a filter that passes all 845 rows of an image and room for every
+    box: the per-image segment runs the large-segment path (waiting rows, flushes)."""
+    P, DN = pkg.params, pkg.DetectNet
+    pred = pkg.synthetic.make_reference_head(3, seed=21)
+    for conf, nms, mb in ((0.0, 0.5, 845), (0.0, 0.3, 100), (0.02, 0.7, 845)):
+        monkeypatch.setattr(P, "object_conf", conf)
+        monkeypatch.setattr(P, "nms_conf", nms)
+        monkeypatch.setattr(P, "max_boxes", mb)
+        want = ref_oracle(pred.numpy(), P)
+        assert want[4].max() > 512
+        assert_ref_equal(DN.detect(pred.to(dev)), want, 3)
+
+
 def test_v3_empty_result_returns_zero(pkg, dev):
     util = pkg.util
     pred = torch.zeros((2, 100, 10), device=dev)
