@@ -31,8 +31,8 @@ def test_workspace_sizes(pkg):
                              for g in (13, 26, 52)])
     small = lib.yp_detect_yolov3_workspace_bytes(heads, 3, 1, 5)
     big = lib.yp_detect_yolov3_workspace_bytes(heads, 3, 64, 5)
-    # 30 tiles of 384 slots per image, 65 bytes of scratch per slot
-    assert small >= 30 * 384 * 65 and small % 256 == 0
+    # 30 tiles of 384 slots per image, 69 bytes of scratch per slot
+    assert small >= 30 * 384 * 69 and small % 256 == 0
     assert 64 * small >= big > 32 * small
     assert lib.yp_detect_yolov3_workspace_bytes(heads, 0, 1, 5) == 0
     assert lib.yp_detect_yolov3_workspace_bytes(heads, 3, 0, 5) == 0
