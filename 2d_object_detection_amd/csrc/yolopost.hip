@@ -457,16 +457,27 @@ __global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBu
             const int packed = reinterpret_cast<const int *>(st)[5];
             const int sa = packed >> 24, scell = packed & 0xffffff;
             const int row = scell / g.gw, col = scell - row * g.gw;
-            const float obj = yp_sigmoid(st[4]);
-            const float cx = (yp_sigmoid(st[0]) + (float)col) * g.sx;
-            const float cy = (yp_sigmoid(st[1]) + (float)row) * g.sy;
-            const float w = (yp_exp(st[2]) * g.anc[2 * sa + 0]) * g.sx;
-            const float hgt = (yp_exp(st[3]) * g.anc[2 * sa + 1]) * g.sy;
-            float best = yp_sigmoid(st[6]);
+            // all 5 + CS exponentials of the row in one staged evaluation (independent chains
+            // interleaved); sigmoid(x) = 1 / (1 + exp(-x)) as in yp_sigmoid
+            float arg[V], e[V];
+            arg[0] = -st[0];
+            arg[1] = -st[1];
+            arg[2] = st[2];
+            arg[3] = st[3];
+            arg[4] = -st[4];
+#pragma unroll
+            for (int j = 0; j < CS; ++j) arg[5 + j] = -st[6 + j];
+            yp_exp_staged<V>(arg, e);
+            const float obj = 1.0f / (1.0f + e[4]);
+            const float cx = (1.0f / (1.0f + e[0]) + (float)col) * g.sx;
+            const float cy = (1.0f / (1.0f + e[1]) + (float)row) * g.sy;
+            const float w = (e[2] * g.anc[2 * sa + 0]) * g.sx;
+            const float hgt = (e[3] * g.anc[2 * sa + 1]) * g.sy;
+            float best = 1.0f / (1.0f + e[5]);
             int bi = 0;
 #pragma unroll
             for (int j = 1; j < CS; ++j) {
-                const float sc = yp_sigmoid(st[6 + j]);
+                const float sc = 1.0f / (1.0f + e[5 + j]);
                 if (sc > best) { best = sc; bi = j; }
             }
             const float hw = w * 0.5f, hh = hgt * 0.5f;

@@ -54,6 +54,57 @@ YP_HD float yp_exp(float x)
 
 YP_HD float yp_sigmoid(float x) { return 1.0f / (1.0f + yp_exp(-x)); }
 
+// yp_exp of N independent arguments, written stage by stage so that neighbouring instructions
+// belong to different arguments (a single wave then issues back to back instead of waiting
+// for each dependent result).  Every element goes through exactly the operations of yp_exp,
+// in the same order, so y[i] == yp_exp(x[i]) bit for bit.
+template <int N>
+YP_HD void yp_exp_staged(const float *x, float *y)
+{
+    const float hi = 88.72283935546875f, lo = -103.97207641601562f;
+    float xc[N], kf[N], r[N], p[N], r2[N];
+#define YP_STAGE for (int i = 0; i < N; ++i)
+#pragma unroll
+    YP_STAGE xc[i] = x[i] > hi ? hi : x[i];
+#pragma unroll
+    YP_STAGE xc[i] = xc[i] < lo ? lo : xc[i];
+#pragma unroll
+    YP_STAGE kf[i] = __builtin_floorf(__builtin_fmaf(xc[i], 1.44269504088896341f, 0.5f));
+#pragma unroll
+    YP_STAGE r[i] = __builtin_fmaf(kf[i], -0.693359375f, xc[i]);
+#pragma unroll
+    YP_STAGE r[i] = __builtin_fmaf(kf[i], 2.12194440e-4f, r[i]);
+#pragma unroll
+    YP_STAGE p[i] = __builtin_fmaf(1.9875691500e-4f, r[i], 1.3981999507e-3f);
+#pragma unroll
+    YP_STAGE p[i] = __builtin_fmaf(p[i], r[i], 8.3334519073e-3f);
+#pragma unroll
+    YP_STAGE p[i] = __builtin_fmaf(p[i], r[i], 4.1665795894e-2f);
+#pragma unroll
+    YP_STAGE p[i] = __builtin_fmaf(p[i], r[i], 1.6666665459e-1f);
+#pragma unroll
+    YP_STAGE p[i] = __builtin_fmaf(p[i], r[i], 5.0000001201e-1f);
+#pragma unroll
+    YP_STAGE r2[i] = r[i] * r[i];
+#pragma unroll
+    YP_STAGE p[i] = __builtin_fmaf(p[i], r2[i], r[i]);
+#pragma unroll
+    YP_STAGE p[i] = p[i] + 1.0f;
+#pragma unroll
+    YP_STAGE {
+        const int k = (x[i] == x[i]) ? (int)kf[i] : 0;
+        const int k1 = k >> 1;
+        const int k2 = k - k1;
+        const float s1 = yp_bits2f((uint32_t)(k1 + 127) << 23);
+        const float s2 = yp_bits2f((uint32_t)(k2 + 127) << 23);
+        float v = (p[i] * s1) * s2;
+        v = x[i] > hi ? __builtin_inff() : v;
+        v = x[i] < lo ? 0.0f : v;
+        y[i] = (x[i] == x[i]) ? v : x[i];
+    }
+#undef YP_STAGE
+}
+
 // A box as four floats.  YOLOv3 mode: (x1,y1,x2,y2).  Reference mode: (y1,x1,y2,x2).
 struct YpBox {
     float a, b, c, d;

@@ -14,6 +14,8 @@ SRC = r'''
 #include "yp_math.h"
 extern "C" {
 void hm_exp(const float* x, float* y, int n) { for (int i = 0; i < n; ++i) y[i] = yp_exp(x[i]); }
+void hm_exp_staged(const float* x, float* y, int n) {   /* n must be a multiple of 10 */
+  for (int i = 0; i + 10 <= n; i += 10) yp_exp_staged<10>(x + i, y + i); }
 void hm_sigmoid(const float* x, float* y, int n) { for (int i = 0; i < n; ++i) y[i] = yp_sigmoid(x[i]); }
 float hm_iou_v3(const float* a, const float* b) {
   YpBox p = {a[0], a[1], a[2], a[3]}, q = {b[0], b[1], b[2], b[3]};
@@ -63,6 +65,11 @@ def test_exp_and_sigmoid_bits_match_oracle(hm):
     assert np.array_equal(y.view(np.uint32), oracle.exp_spec(xs).view(np.uint32))
     hm.hm_sigmoid(_p(xs), _p(y), xs.size)
     assert np.array_equal(y.view(np.uint32), oracle.sigmoid(xs).view(np.uint32))
+    # the staged form used by the front kernels' dense decode: same bits, NaN included
+    xs10 = np.concatenate([xs, np.array([np.nan], np.float32)])[:(xs.size + 1) // 10 * 10].copy()
+    y10 = np.empty_like(xs10)
+    hm.hm_exp_staged(_p(xs10), _p(y10), xs10.size)
+    assert np.array_equal(y10.view(np.uint32), oracle.exp_spec(xs10).view(np.uint32))
 
 
 def test_iou_bits_match_oracle(hm):
