@@ -115,8 +115,8 @@ def main():
     cpu_heads, heads = make_device_heads(batch, inp_dim, seed + 100 * rank, dev, args.clustered)
     rows_per_image = syn.anchors_per_image(inp_dim if isinstance(inp_dim, int) else tuple(inp_dim))
 
-    # Two engines (own workspace and output buffers) on two HIP streams: consecutive batches
-    # are independent, so the decode of batch i+1 overlaps the NMS of batch i.  With ranks
+    # n_eng engines (own workspace and output buffers), each on its own HIP stream: consecutive
+    # batches are independent, so the decode of batch i+1 overlaps the NMS of batch i.  With ranks
     # exchanging results, each engine writes straight into the payload of its gather buffer.
     n_eng = max(1, args.in_flight)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_eng)]
