@@ -17,6 +17,7 @@
 
 #include "yolopost.h"
 #include "yp_math.h"
+#include "yp_tile.h"
 
 namespace {
 
@@ -26,44 +27,70 @@ struct GradAnchors {
 
 constexpr int kGradMaxClasses = 64;
 
-__global__ void __launch_bounds__(256)
+template <bool STAGED>
+__global__ void __launch_bounds__(kTileRows)
 k_decode_grid_ref_backward(const float *__restrict__ pred, int H, int W, int A, int C, GradAnchors at,
                            const float *__restrict__ g_center, const float *__restrict__ g_wh,
                            const float *__restrict__ g_obj, const float *__restrict__ g_cls,
                            float *__restrict__ g_pred, long long total)
 {
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= total) return;
+    // STAGED: [0, 256 V) the raw rows, later the gradient rows; [256 V, 256 (V + C)) the upstream
+    // class gradients (yp_tile.h)
+    extern __shared__ float s_tile[];
+    const long long tile0 = (long long)blockIdx.x * kTileRows;
+    const long long o = tile0 + threadIdx.x;
     const int V = 5 + C;
-    const int a = (int)(o % A);
-    const float *t = pred + o * V;
-    float *gt = g_pred + o * V;
-    const float fh = (float)H, fw = (float)W;  // detect_net.py:163: x is divided by H, y by W
-    float2 gc = {0.0f, 0.0f}, gw = {0.0f, 0.0f};
-    if (g_center) gc = reinterpret_cast<const float2 *>(g_center)[o];
-    if (g_wh) gw = reinterpret_cast<const float2 *>(g_wh)[o];
-    const float go = g_obj ? g_obj[o] : 0.0f;
-    const float s0 = yp_sigmoid(t[0]), s1 = yp_sigmoid(t[1]);
-    gt[0] = (gc.x / fh) * ((1.0f - s0) * s0);
-    gt[1] = (gc.y / fw) * ((1.0f - s1) * s1);
-    const float w0 = (yp_exp(t[2]) * at.anc[2 * a + 0]) / fh;
-    const float w1 = (yp_exp(t[3]) * at.anc[2 * a + 1]) / fw;
-    gt[2] = gw.x * w0;
-    gt[3] = gw.y * w1;
-    const float so = yp_sigmoid(t[4]);
-    gt[4] = go * ((1.0f - so) * so);
-    if (!g_cls) {
-        for (int j = 0; j < C; ++j) gt[5 + j] = 0.0f;
-        return;
+    float *s_gcls = s_tile + kTileRows * V;
+    if (STAGED) {
+        if (g_cls) yp_tile_load(g_cls + tile0 * C, (total - tile0) * C, C, s_gcls);
+        yp_tile_load(pred + tile0 * V, (total - tile0) * V, V, s_tile);
     }
-    float m = t[5];
-    for (int j = 1; j < C; ++j) m = t[5 + j] > m ? t[5 + j] : m;
-    float s = 0.0f;
-    for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
-    const float *gp = g_cls + o * C;
-    float dot = 0.0f;
-    for (int j = 0; j < C; ++j) dot = dot + gp[j] * (yp_exp(t[5 + j] - m) / s);
-    for (int j = 0; j < C; ++j) gt[5 + j] = (gp[j] - dot) * (yp_exp(t[5 + j] - m) / s);
+    float gt[STAGED ? kTileMaxWidth : 5];
+    if (o < total) {
+        const int a = (int)(o % A);
+        const float *t = STAGED ? s_tile + threadIdx.x * V : pred + o * V;
+        const float fh = (float)H, fw = (float)W;  // detect_net.py:163: x is divided by H, y by W
+        float2 gc = {0.0f, 0.0f}, gw = {0.0f, 0.0f};
+        if (g_center) gc = reinterpret_cast<const float2 *>(g_center)[o];
+        if (g_wh) gw = reinterpret_cast<const float2 *>(g_wh)[o];
+        const float go = g_obj ? g_obj[o] : 0.0f;
+        const float s0 = yp_sigmoid(t[0]), s1 = yp_sigmoid(t[1]);
+        gt[0] = (gc.x / fh) * ((1.0f - s0) * s0);
+        gt[1] = (gc.y / fw) * ((1.0f - s1) * s1);
+        const float w0 = (yp_exp(t[2]) * at.anc[2 * a + 0]) / fh;
+        const float w1 = (yp_exp(t[3]) * at.anc[2 * a + 1]) / fw;
+        gt[2] = gw.x * w0;
+        gt[3] = gw.y * w1;
+        const float so = yp_sigmoid(t[4]);
+        gt[4] = go * ((1.0f - so) * so);
+        float m = t[5];
+        for (int j = 1; j < C; ++j) m = t[5 + j] > m ? t[5 + j] : m;
+        float s = 0.0f;
+        for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
+        const float *gp = STAGED ? s_gcls + threadIdx.x * C : g_cls + o * C;
+        float dot = 0.0f;
+        if (g_cls)
+            for (int j = 0; j < C; ++j) dot = dot + gp[j] * (yp_exp(t[5 + j] - m) / s);
+        if (STAGED) {
+#pragma unroll
+            for (int j = 0; j < kTileMaxWidth - 5; ++j)
+                if (j < C) gt[5 + j] = g_cls ? (gp[j] - dot) * (yp_exp(t[5 + j] - m) / s) : 0.0f;
+        } else {
+            float *out = g_pred + o * V;
+            for (int v = 0; v < 5; ++v) out[v] = gt[v];
+            for (int j = 0; j < C; ++j)
+                out[5 + j] = g_cls ? (gp[j] - dot) * (yp_exp(t[5 + j] - m) / s) : 0.0f;
+        }
+    }
+    if (STAGED) {
+        __syncthreads();   // every thread has read its raw row: the buffer now takes the results
+        if (o < total) {
+#pragma unroll
+            for (int v = 0; v < kTileMaxWidth; ++v)
+                if (v < V) s_tile[threadIdx.x * V + v] = gt[v];
+        }
+        yp_tile_store(g_pred + tile0 * V, (total - tile0) * V, V, s_tile);
+    }
 }
 
 // ---- fused loss_custom: forward value and gradient of the raw head in one pass ------------
@@ -84,23 +111,34 @@ struct LossWeights {
 
 constexpr int kLossThreads = 256;
 
+template <bool STAGED>
 __global__ void __launch_bounds__(kLossThreads)
 k_loss_custom_ref(const float *__restrict__ pred, const float *__restrict__ truth, int H, int W, int A,
                   int C, GradAnchors at, LossWeights lw, float *__restrict__ g_pred,
                   float *__restrict__ partials, long long total)
 {
+    // STAGED: [0, 256 V) the raw rows, later the gradient rows; then 256 x 5 target values
+    extern __shared__ float s_tile[];
     __shared__ float s_red[3][kLossThreads / 64];
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    static_assert(kLossThreads == kTileRows, "one record per thread");
+    const long long tile0 = (long long)blockIdx.x * kTileRows;
+    const long long o = tile0 + threadIdx.x;
+    const int V = 5 + C;
+    float *s_truth = s_tile + kTileRows * V;
+    if (STAGED) {
+        yp_tile_load(truth + tile0 * 5, (total - tile0) * 5, 5, s_truth);
+        yp_tile_load(pred + tile0 * V, (total - tile0) * V, V, s_tile);
+    }
     float l_conf = 0.0f, l_cls = 0.0f, l_coord = 0.0f;
+    float gt[STAGED ? kTileMaxWidth : 5];
     if (o < total) {
-        const int V = 5 + C;
         const int N = H * W * A;
         const int n = (int)(o % N);
         const int a = n % A, k = n / A;
         const float gx = (float)(k % H), gy = (float)(k / H);  // detect_net.py:155-162
         const float fh = (float)H, fw = (float)W;
-        const float *t = pred + o * V;
-        const float *y = truth + o * 5;
+        const float *t = STAGED ? s_tile + threadIdx.x * V : pred + o * V;
+        const float *y = STAGED ? s_truth + threadIdx.x * 5 : truth + o * 5;
         const float s0 = yp_sigmoid(t[0]), s1 = yp_sigmoid(t[1]);
         const float c0 = (s0 + gx) / fh, c1 = (s1 + gy) / fw;
         const float w0 = (yp_exp(t[2]) * at.anc[2 * a + 0]) / fh;
@@ -139,7 +177,6 @@ k_loss_custom_ref(const float *__restrict__ pred, const float *__restrict__ trut
             dot = dot + (-(m * e)) * p;
         }
         if (g_pred) {
-            float *gt = g_pred + o * V;
             // d total / d output (the 0.5 cancels the 2 of each square)
             const float g_c0 = -(lw.coord_w * m * d0), g_c1 = -(lw.coord_w * m * d1);
             const float g_w0 = -(lw.coord_w * m * d2), g_w1 = -(lw.coord_w * m * d3);
@@ -149,12 +186,34 @@ k_loss_custom_ref(const float *__restrict__ pred, const float *__restrict__ trut
             gt[2] = g_w0 * w0;
             gt[3] = g_w1 * w1;
             gt[4] = g_ob * ((1.0f - ob) * ob);
-            for (int j = 0; j < C; ++j) {
-                const float p = yp_exp(t[5 + j] - mx) / se;
-                const float e = ((j == cls_id) ? 1.0f : 0.0f) - p;
-                gt[5 + j] = (-(m * e) - dot) * p;
+            if (STAGED) {
+#pragma unroll
+                for (int j = 0; j < kTileMaxWidth - 5; ++j) {
+                    if (j < C) {
+                        const float p = yp_exp(t[5 + j] - mx) / se;
+                        const float e = ((j == cls_id) ? 1.0f : 0.0f) - p;
+                        gt[5 + j] = (-(m * e) - dot) * p;
+                    }
+                }
+            } else {
+                float *out = g_pred + o * V;
+                for (int v = 0; v < 5; ++v) out[v] = gt[v];
+                for (int j = 0; j < C; ++j) {
+                    const float p = yp_exp(t[5 + j] - mx) / se;
+                    const float e = ((j == cls_id) ? 1.0f : 0.0f) - p;
+                    out[5 + j] = (-(m * e) - dot) * p;
+                }
             }
         }
+    }
+    if (STAGED && g_pred) {
+        __syncthreads();   // every thread has read its raw row: the buffer now takes the results
+        if (o < total) {
+#pragma unroll
+            for (int v = 0; v < kTileMaxWidth; ++v)
+                if (v < V) s_tile[threadIdx.x * V + v] = gt[v];
+        }
+        yp_tile_store(g_pred + tile0 * V, (total - tile0) * V, V, s_tile);
     }
     float v[3] = {l_conf, l_cls, l_coord};
 #pragma unroll
@@ -173,12 +232,14 @@ k_loss_custom_ref(const float *__restrict__ pred, const float *__restrict__ trut
 }
 
 // One workgroup adds the per-workgroup partial sums in binary64, in a fixed order.
-__global__ void __launch_bounds__(kLossThreads)
+constexpr int kFinishThreads = 1024;
+
+__global__ void __launch_bounds__(kFinishThreads)
 k_loss_finish(const float *__restrict__ partials, int blocks, float *__restrict__ loss)
 {
-    __shared__ double s_red[3][kLossThreads / 64];
+    __shared__ double s_red[3][kFinishThreads / 64];
     double v[3] = {0.0, 0.0, 0.0};
-    for (int i = (int)threadIdx.x; i < blocks; i += kLossThreads)
+    for (int i = (int)threadIdx.x; i < blocks; i += kFinishThreads)
         for (int q = 0; q < 3; ++q) v[q] += (double)partials[(size_t)i * 3 + q];
     for (int q = 0; q < 3; ++q) {
         double x = v[q];
@@ -190,7 +251,7 @@ k_loss_finish(const float *__restrict__ partials, int blocks, float *__restrict_
         double sum[3];
         for (int q = 0; q < 3; ++q) {
             sum[q] = 0.0;
-            for (int w = 0; w < kLossThreads / 64; ++w) sum[q] += s_red[q][w];
+            for (int w = 0; w < kFinishThreads / 64; ++w) sum[q] += s_red[q][w];
         }
         loss[0] = (float)(0.5 * (sum[0] + sum[1] + sum[2]));  // train.py:195
         loss[1] = (float)sum[0];
@@ -231,12 +292,19 @@ extern "C" int yp_loss_custom_reference(const float *d_pred, const float *d_true
     for (int k = 0; k < 2 * YP_MAX_ANCHORS; ++k) at.anc[k] = k < 2 * num_anchors ? anchors[k] : 0.0f;
     const LossWeights lw = {coord_weight, obj_weight, noobj_weight, iou_thr};
     float *partials = (float *)d_workspace;
-    hipLaunchKernelGGL(k_loss_custom_ref, dim3((unsigned)blocks), dim3(kLossThreads), 0,
-                       (hipStream_t)stream, d_pred, d_true_grid, grid_h, grid_w, num_anchors,
-                       num_classes, at, lw, d_grad_pred, partials, total);
+    const int V = 5 + num_classes;
+    if (V <= kTileMaxWidth)
+        hipLaunchKernelGGL(k_loss_custom_ref<true>, dim3((unsigned)blocks), dim3(kLossThreads),
+                           (size_t)kTileRows * (V + 5) * sizeof(float), (hipStream_t)stream, d_pred,
+                           d_true_grid, grid_h, grid_w, num_anchors, num_classes, at, lw, d_grad_pred,
+                           partials, total);
+    else
+        hipLaunchKernelGGL(k_loss_custom_ref<false>, dim3((unsigned)blocks), dim3(kLossThreads), 0,
+                           (hipStream_t)stream, d_pred, d_true_grid, grid_h, grid_w, num_anchors,
+                           num_classes, at, lw, d_grad_pred, partials, total);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(kLossThreads), 0, (hipStream_t)stream, partials,
+    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(kFinishThreads), 0, (hipStream_t)stream, partials,
                        (int)blocks, d_loss);
     return (int)hipGetLastError();
 }
@@ -255,8 +323,15 @@ extern "C" int yp_predict_transform_reference_backward(
     const long long total = (long long)batch * grid_h * grid_w * num_anchors;
     const long long blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return YP_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_decode_grid_ref_backward, dim3((unsigned)blocks), dim3(256), 0,
-                       (hipStream_t)stream, d_pred, grid_h, grid_w, num_anchors, num_classes, at,
-                       d_grad_center, d_grad_wh, d_grad_obj, d_grad_cls, d_grad_pred, total);
+    const int V = 5 + num_classes;
+    if (V <= kTileMaxWidth)
+        hipLaunchKernelGGL(k_decode_grid_ref_backward<true>, dim3((unsigned)blocks), dim3(kTileRows),
+                           (size_t)kTileRows * (V + num_classes) * sizeof(float), (hipStream_t)stream,
+                           d_pred, grid_h, grid_w, num_anchors, num_classes, at, d_grad_center,
+                           d_grad_wh, d_grad_obj, d_grad_cls, d_grad_pred, total);
+    else
+        hipLaunchKernelGGL(k_decode_grid_ref_backward<false>, dim3((unsigned)blocks), dim3(kTileRows), 0,
+                           (hipStream_t)stream, d_pred, grid_h, grid_w, num_anchors, num_classes, at,
+                           d_grad_center, d_grad_wh, d_grad_obj, d_grad_cls, d_grad_pred, total);
     return (int)hipGetLastError();
 }

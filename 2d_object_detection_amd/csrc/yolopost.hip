@@ -26,6 +26,7 @@
 
 #include "yolopost.h"
 #include "yp_math.h"
+#include "yp_tile.h"
 
 namespace {
 
@@ -496,14 +497,19 @@ __global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBu
 // ---------------------------------------------------------------- front: reference head
 // Thread t <-> row n = tile*256 + t of image b; a row is the V contiguous floats of one
 // (row, col, anchor) (detect_net.py:153).
+template <bool STAGED>
 __global__ void k_front_grid_ref(const float *pred, int H, int W, int A, int C,
                                  AnchorTable at, CandBuf cb, float conf, float im_h,
                                  float im_w)
 {
     __shared__ u64 s_bal[kRowTile / 64];
+    extern __shared__ float s_tile[];
+    static_assert(kRowTile == kTileRows, "one record per thread");
     const int tile = blockIdx.x, b = blockIdx.y;
     const int N = H * W * A, V = 5 + C;
     const int n = tile * kRowTile + threadIdx.x;
+    const float *tile_src = pred + ((size_t)b * N + (size_t)tile * kRowTile) * V;
+    if (STAGED) yp_tile_load(tile_src, (long long)(N - tile * kRowTile) * V, V, s_tile);
     bool pass = false;
     YpBox bx = {0.f, 0.f, 0.f, 0.f};
     float best = 0.f;
@@ -511,7 +517,7 @@ __global__ void k_front_grid_ref(const float *pred, int H, int W, int A, int C,
     if (n < N) {
         const int a = n % A, k = n / A;
         const float gx = (float)(k % H), gy = (float)(k / H);   // detect_net.py:155-162
-        const float *t = pred + ((size_t)b * N + n) * V;
+        const float *t = STAGED ? s_tile + threadIdx.x * V : tile_src + (size_t)threadIdx.x * V;
         const float cx = (yp_sigmoid(t[0]) + gx) / (float)H;    // :166-168
         const float cy = (yp_sigmoid(t[1]) + gy) / (float)W;
         const float obj = yp_sigmoid(t[4]);                     // :171
@@ -576,18 +582,22 @@ __global__ void k_front_split_ref(const float *center, const float *wh, const fl
 }
 
 // ------------------------------------------------------------ front: decoded YOLOv3 rows
+template <bool STAGED>
 __global__ void k_front_rows_v3(const float *rows, int N, int C, CandBuf cb, float conf)
 {
     __shared__ u64 s_bal[kRowTile / 64];
+    extern __shared__ float s_tile[];
     const int tile = blockIdx.x, b = blockIdx.y;
     const int V = 5 + C;
     const int n = tile * kRowTile + threadIdx.x;
+    const float *tile_src = rows + ((size_t)b * N + (size_t)tile * kRowTile) * V;
+    if (STAGED) yp_tile_load(tile_src, (long long)(N - tile * kRowTile) * V, V, s_tile);
     bool pass = false;
     YpBox bx = {0.f, 0.f, 0.f, 0.f};
     float best = 0.f, ob = 0.f;
     int bi = 0;
     if (n < N) {
-        const float *p = rows + ((size_t)b * N + n) * V;
+        const float *p = STAGED ? s_tile + threadIdx.x * V : tile_src + (size_t)threadIdx.x * V;
         ob = p[4];
         pass = (ob > conf) && (ob != 0.0f);
         if (pass) {
@@ -1509,30 +1519,52 @@ __global__ void k_decode_heads_v3(HeadsArgs ha, float *out_rows)
     for (int i = threadIdx.x; i < nflt; i += blockDim.x) dst[i] = s_tile[i];
 }
 
-// Reference predict_transform (detect_net.py:152-183): thread <-> row.
+// Reference predict_transform (detect_net.py:152-183): thread <-> row.  The raw rows come in,
+// and the class probabilities go out, through the tile staging of yp_tile.h.
+template <bool STAGED>
 __global__ void k_decode_grid_ref(const float *pred, int H, int W, int A, int C, AnchorTable at,
                                   float *center, float *wh, float *obj, float *cls, long long total)
 {
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= total) return;
+    extern __shared__ float s_tile[];
+    const long long tile0 = (long long)blockIdx.x * kTileRows;
+    const long long o = tile0 + threadIdx.x;
     const int N = H * W * A, V = 5 + C;
-    const int n = (int)(o % N);
-    const int a = n % A, k = n / A;
-    const float gx = (float)(k % H), gy = (float)(k / H);
-    const float *t = pred + o * V;
-    float2 ce, sz;
-    ce.x = (yp_sigmoid(t[0]) + gx) / (float)H;
-    ce.y = (yp_sigmoid(t[1]) + gy) / (float)W;
-    sz.x = (yp_exp(t[2]) * at.anc[2 * a + 0]) / (float)H;
-    sz.y = (yp_exp(t[3]) * at.anc[2 * a + 1]) / (float)W;
-    reinterpret_cast<float2 *>(center)[o] = ce;
-    reinterpret_cast<float2 *>(wh)[o] = sz;
-    obj[o] = yp_sigmoid(t[4]);
-    float m = t[5];
-    for (int j = 1; j < C; ++j) m = t[5 + j] > m ? t[5 + j] : m;
-    float s = 0.f;
-    for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
-    for (int j = 0; j < C; ++j) cls[o * C + j] = yp_exp(t[5 + j] - m) / s;
+    if (STAGED) yp_tile_load(pred + tile0 * V, (total - tile0) * V, V, s_tile);
+    float probs[STAGED ? kTileMaxWidth : 1];
+    if (o < total) {
+        const int n = (int)(o % N);
+        const int a = n % A, k = n / A;
+        const float gx = (float)(k % H), gy = (float)(k / H);
+        const float *t = STAGED ? s_tile + threadIdx.x * V : pred + o * V;
+        float2 ce, sz;
+        ce.x = (yp_sigmoid(t[0]) + gx) / (float)H;
+        ce.y = (yp_sigmoid(t[1]) + gy) / (float)W;
+        sz.x = (yp_exp(t[2]) * at.anc[2 * a + 0]) / (float)H;
+        sz.y = (yp_exp(t[3]) * at.anc[2 * a + 1]) / (float)W;
+        reinterpret_cast<float2 *>(center)[o] = ce;
+        reinterpret_cast<float2 *>(wh)[o] = sz;
+        obj[o] = yp_sigmoid(t[4]);
+        float m = t[5];
+        for (int j = 1; j < C; ++j) m = t[5 + j] > m ? t[5 + j] : m;
+        float s = 0.f;
+        for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
+        if (STAGED) {
+#pragma unroll
+            for (int j = 0; j < kTileMaxWidth; ++j)
+                if (j < C) probs[j] = yp_exp(t[5 + j] - m) / s;
+        } else {
+            for (int j = 0; j < C; ++j) cls[o * C + j] = yp_exp(t[5 + j] - m) / s;
+        }
+    }
+    if (STAGED) {
+        __syncthreads();   // every thread has read its raw row: the buffer now takes the results
+        if (o < total) {
+#pragma unroll
+            for (int j = 0; j < kTileMaxWidth; ++j)
+                if (j < C) s_tile[threadIdx.x * C + j] = probs[j];
+        }
+        yp_tile_store(cls + tile0 * C, (total - tile0) * C, C, s_tile);
+    }
 }
 
 __global__ void k_bbox_iou(const float *box1, const float *boxes2, int m, int row_stride,
@@ -1826,10 +1858,16 @@ int yp_predict_transform_reference(const float *d_pred, int batch, int grid_h, i
     for (int i = 0; i < 2 * num_anchors; ++i) at.anc[i] = anchors[i];
     const long long total = (long long)batch * grid_h * grid_w * num_anchors;
     if (total >= (1ll << 31)) return YP_ERR_UNSUPPORTED;
-    const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(k_decode_grid_ref, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_pred,
-                       grid_h, grid_w, num_anchors, num_classes, at, d_center, d_wh, d_obj, d_cls,
-                       total);
+    const int blocks = (int)((total + kTileRows - 1) / kTileRows);
+    const size_t lds = yp_tile_lds_bytes(5 + num_classes);
+    if (lds)
+        hipLaunchKernelGGL(k_decode_grid_ref<true>, dim3(blocks), dim3(kTileRows), lds,
+                           (hipStream_t)stream, d_pred, grid_h, grid_w, num_anchors, num_classes, at,
+                           d_center, d_wh, d_obj, d_cls, total);
+    else
+        hipLaunchKernelGGL(k_decode_grid_ref<false>, dim3(blocks), dim3(kTileRows), 0,
+                           (hipStream_t)stream, d_pred, grid_h, grid_w, num_anchors, num_classes, at,
+                           d_center, d_wh, d_obj, d_cls, total);
     return (int)hipGetLastError();
 }
 
@@ -1945,8 +1983,13 @@ int yp_write_results(const float *d_rows, int rows_per_image, const YpParams *pa
     carve(d_workspace, slots, tiles, (size_t)params->batch * params->num_classes, &w);
     CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile};
     hipStream_t st = (hipStream_t)stream;
-    YP_LAUNCH(0, k_front_rows_v3, dim3(tpi, params->batch), dim3(kRowTile), 0, st, d_rows,
-              rows_per_image, params->num_classes, cb, params->conf_thr);
+    const size_t lds = yp_tile_lds_bytes(5 + params->num_classes);
+    if (lds)
+        YP_LAUNCH(0, k_front_rows_v3<true>, dim3(tpi, params->batch), dim3(kRowTile), lds, st, d_rows,
+                  rows_per_image, params->num_classes, cb, params->conf_thr);
+    else
+        YP_LAUNCH(0, k_front_rows_v3<false>, dim3(tpi, params->batch), dim3(kRowTile), 0, st, d_rows,
+                  rows_per_image, params->num_classes, cb, params->conf_thr);
     return finish_v3(w, params, (int)spi, tpi, kRowTile, d_out_rows, out_cap, d_out_count, d_stats,
                      st);
 }
@@ -1985,9 +2028,15 @@ int yp_detect_reference(const YpHead *head, const YpParams *params, float *d_out
     AnchorTable at = {};
     for (int i = 0; i < 2 * head->num_anchors; ++i) at.anc[i] = head->anchors[i];
     hipStream_t st = (hipStream_t)stream;
-    YP_LAUNCH(0, k_front_grid_ref, dim3(tpi, params->batch), dim3(kRowTile), 0, st, head->data,
-              head->grid_h, head->grid_w, head->num_anchors, params->num_classes, at, cb,
-              params->conf_thr, params->im_h, params->im_w);
+    const size_t lds = yp_tile_lds_bytes(5 + params->num_classes);
+    if (lds)
+        YP_LAUNCH(0, k_front_grid_ref<true>, dim3(tpi, params->batch), dim3(kRowTile), lds, st,
+                  head->data, head->grid_h, head->grid_w, head->num_anchors, params->num_classes, at,
+                  cb, params->conf_thr, params->im_h, params->im_w);
+    else
+        YP_LAUNCH(0, k_front_grid_ref<false>, dim3(tpi, params->batch), dim3(kRowTile), 0, st,
+                  head->data, head->grid_h, head->grid_w, head->num_anchors, params->num_classes, at,
+                  cb, params->conf_thr, params->im_h, params->im_w);
     return finish_ref(w, params, (int)spi, tpi, kRowTile, d_out_boxes, d_out_scores, d_out_classes,
                       d_out_index, d_out_counts, d_surv_counts, st);
 }
