@@ -386,6 +386,45 @@ def test_ref_ragged_counts_pack_as_object_array(pkg, dev, monkeypatch):
     assert np.asarray(boxes[1]).shape == (0, 4)
 
 
+def test_v3_randomised_shapes_and_thresholds(pkg, dev):
+    """A seeded sweep over input sizes (square, rectangular, cell counts that are not multiples
+    of the tile), class counts, thresholds and box statistics: the fused path and the oracle
+    must agree bit for bit on every case."""
+    syn, util = pkg.synthetic, pkg.util
+    rs = np.random.RandomState(2024)
+    dims = [96, 160, 224, 320, 416, (96, 160), (224, 128), (352, 608), (640, 96)]
+    for case in range(60):
+        inp = dims[rs.randint(len(dims))]
+        B = int(rs.randint(1, 5))
+        C = int(rs.choice([1, 2, 5, 5, 5, 7, 20]))
+        conf = float(rs.choice([0.001, 0.05, 0.3, 0.5, 0.5, 0.7, 0.95]))
+        nms = float(rs.choice([0.0, 0.2, 0.4, 0.45, 0.7, 1.0]))
+        clustered = bool(rs.randint(2))
+        seed = int(rs.randint(1 << 20))
+        heads = syn.make_heads(B, inp, num_classes=C, seed=seed, clustered=clustered)
+        want, surv, _ = v3_oracle(heads, inp, syn.YOLOV3_ANCHORS, C, conf, nms)
+        eng = util.YoloV3Post(B, inp, C, conf, nms, device=dev)
+        got = eng.detect([h.to(dev) for h in heads]).cpu().numpy()
+        tag = (case, inp, B, C, conf, nms, clustered, seed)
+        assert got.shape == want.shape, tag
+        assert np.array_equal(got, want), tag
+        assert np.array_equal(eng.segment_stats()[0].sum(1), surv), tag
+
+
+def test_ref_randomised_params(pkg, dev, monkeypatch):
+    P, DN = pkg.params, pkg.DetectNet
+    rs = np.random.RandomState(77)
+    for case in range(16):
+        B = int(rs.randint(1, 9))
+        monkeypatch.setattr(P, "object_conf", float(rs.choice([0.0, 0.05, 0.2, 0.4, 0.6, 0.8])))
+        monkeypatch.setattr(P, "nms_conf", float(rs.choice([0.0, 0.1, 0.3, 0.5, 0.9, 1.0])))
+        monkeypatch.setattr(P, "max_boxes", int(rs.choice([1, 5, 20, 100, 845])))
+        pred = pkg.synthetic.make_reference_head(B, seed=int(rs.randint(1 << 20)), relu=bool(rs.randint(2)))
+        want = ref_oracle(pred.numpy(), P)
+        assert_ref_equal(DN.detect(pred.to(dev)), want, B)
+        assert_ref_equal(DN.filter_boxes(DN.predict_transform(pred.to(dev))), want, B)
+
+
 # ----------------------------------------------------------- BASELINE.json full-size configs
 
 def _check_v3_properties(pkg, dev, got, nms, C):
