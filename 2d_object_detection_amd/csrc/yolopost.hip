@@ -372,27 +372,43 @@ __global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBu
     const bool in0 = cell < cells, in1 = cell + 1 < cells;
 
     float t[2][NA][V];
-    // the objectness planes are requested first: the filter and the ranking only need them,
-    // so they run while the other 9 channels of every anchor are still in flight
-    auto load_channel = [&](int a, int v) {
-        const float *pl = g.data + ((size_t)(b * NA + a) * V + v) * cells + cell0;   // scalar
-        const bool wide = ((reinterpret_cast<uintptr_t>(pl) & 7) == 0) && (cell0 + kFrontCells <= cells);
-        if (wide) {     // wave-uniform: whole slice present and 8-byte aligned
-            const float2 q = reinterpret_cast<const float2 *>(pl)[lane];
+    // The objectness planes are requested first: the filter and the ranking only need them,
+    // so they run while the other 9 channels of every anchor are still in flight.  Whether
+    // the 8-byte form can be used is decided once for the whole tile (cell0 is even, so with
+    // an even plane size every plane slice starts on the parity of the head's base address);
+    // otherwise lanes past the last cell read cell 0 of the slice instead of branching.
+    const float *img = g.data + (size_t)b * NA * V * cells + cell0;   // scalar
+    const bool wide = ((reinterpret_cast<uintptr_t>(g.data) & 7) == 0) && ((cells & 1) == 0) &&
+                      (cell0 + kFrontCells <= cells);
+    if (wide) {
+        auto load_channel = [&](int a, int v) {
+            const float2 q = reinterpret_cast<const float2 *>(img + (size_t)(a * V + v) * cells)[lane];
             t[0][a][v] = q.x;
             t[1][a][v] = q.y;
-        } else {
-            t[0][a][v] = in0 ? pl[2 * lane] : 0.0f;
-            t[1][a][v] = in1 ? pl[2 * lane + 1] : 0.0f;
+        };
+#pragma unroll
+        for (int a = 0; a < NA; ++a) load_channel(a, 4);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                if (v != 4) load_channel(a, v);
         }
-    };
+    } else {
+        const int i0 = in0 ? 2 * lane : 0, i1 = in1 ? 2 * lane + 1 : 0;
+        auto load_channel = [&](int a, int v) {
+            const float *pl = img + (size_t)(a * V + v) * cells;
+            t[0][a][v] = pl[i0];
+            t[1][a][v] = pl[i1];
+        };
 #pragma unroll
-    for (int a = 0; a < NA; ++a) load_channel(a, 4);
+        for (int a = 0; a < NA; ++a) load_channel(a, 4);
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
+        for (int a = 0; a < NA; ++a) {
 #pragma unroll
-        for (int v = 0; v < V; ++v)
-            if (v != 4) load_channel(a, v);
+            for (int v = 0; v < V; ++v)
+                if (v != 4) load_channel(a, v);
+        }
     }
 #ifdef YP_STAMPS
     if (lane == 0 && ha.dbg) {
