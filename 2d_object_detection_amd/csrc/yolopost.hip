@@ -755,39 +755,35 @@ __device__ __forceinline__ void suppress_words(const YpPrep &pi, bool row_ok, co
     for (int u = 0; u < U; ++u) inter[u] = d0[u] * d1[u];
 #pragma unroll
     for (int u = 0; u < U; ++u) uni[u] = pi.area + aj[u] - inter[u];
-    // verdicts as wave masks: every comparison lands in a scalar register pair, the logic on
-    // them is scalar, and the result already is the ballot
-    const u64 rowm = __ballot(row_ok);
-    const u64 fastm = thr.fast ? ~0ull : 0ull;
-    u64 und[U];
-    u64 any_und = 0ull;
+    // verdict per lane as a small integer (0 no, 1 yes, 2 undecided) kept in vector registers:
+    // the select / or instructions cost vector issue slots but spare the scalar unit, which the
+    // four SIMDs of a CU share and which the mask form of the same logic saturates first
+    int verdict[U];
+    int undecided = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const u64 yes = __ballot(inter[u] > thr.hi * uni[u]);
-        const u64 no = __ballot(inter[u] < thr.lo * uni[u]);
-        const u64 ok = __ballot(uni[u] > 1e-30f);
-        const u64 decided = fastm & ok & (yes | no);
-        u64 sup = decided & yes;
-        u64 open = ~decided;
-        if (MODE == YP_MODE_REFERENCE) {
-            const u64 deg = __ballot((pi.area <= 0.0f) | (aj[u] <= 0.0f));
-            sup = (sup & ~deg) | ((0.0f > thr.thr) ? deg : 0ull);
-            open &= ~deg;
-        }
-        words[u] = sup & rowm;
-        und[u] = open & rowm;
-        any_und |= und[u];
+        const bool yes = inter[u] > thr.hi * uni[u];
+        const bool no = inter[u] < thr.lo * uni[u];
+        // a union above 1e30 needs no guard: the bands then decide "no", which is what the
+        // quotient gives
+        int v = (thr.fast & (uni[u] > 1e-30f) & (yes | no)) ? (yes ? 1 : 0) : 2;
+        if (MODE == YP_MODE_REFERENCE)
+            v = ((pi.area <= 0.0f) | (aj[u] <= 0.0f)) ? ((0.0f > thr.thr) ? 1 : 0) : v;
+        v = row_ok ? v : 0;
+        verdict[u] = v;
+        undecided |= v;
     }
-    if (any_und != 0ull) {   // rare: some quotient sits within 2^-20 of the threshold
+    if (undecided & 2) {   // rare: some quotient sits within 2^-20 of the threshold
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (und[u] != 0ull) {
+            if (verdict[u] == 2) {
                 const YpPrep pj = {cj[u].x, cj[u].y, cj[u].z, cj[u].w, aj[u]};
-                const bool mine = (und[u] >> (threadIdx.x & 63)) & 1ull;
-                words[u] |= __ballot(mine && yp_suppresses_exact<MODE>(pi, pj, thr.thr));
+                verdict[u] = yp_suppresses_exact<MODE>(pi, pj, thr.thr) ? 1 : 0;
             }
         }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) words[u] = __ballot(verdict[u] == 1);
 }
 
 template <int MODE, class Emit>
