@@ -44,7 +44,7 @@ constexpr int kSmallWords = kSmallCap / 64;
 // words of the triangular pairwise bitmask of a kSmallCap segment: sum_w (cap - 64 w)
 constexpr int kMaskWords = kSmallWords * kSmallCap - 32 * kSmallWords * (kSmallWords - 1);
 constexpr int kRawBytes = (kSortCap * 8 > kMaskWords * 8) ? kSortCap * 8 : kMaskWords * 8;
-constexpr int kSmallBytes = 32 * (kSmallCap + 8);
+constexpr int kSmallBytes = 32 * (kSmallCap + 8) + 16 * 32;   // + 32 boxes the pair loop may over-read
 constexpr int kTileCap = 2048;    // tile-count prefix held in LDS up to this many tiles
 
 // ------------------------------------------------------------------------ device structs
@@ -1220,11 +1220,14 @@ void k_segment_nms(SegArgs s)
                 float aj[kPairUnroll], lo0[kPairUnroll], lo1[kPairUnroll], hi0[kPairUnroll],
                     hi1[kPairUnroll], d0[kPairUnroll], d1[kPairUnroll], inter[kPairUnroll],
                     uni[kPairUnroll];
+                // columns j0, j0+8, ... at fixed offsets from one address; a column past K reads
+                // whatever the padded arrays hold and its word is never stored
+                const float4 *cb = lbox + j0;
+                const float *ab = larea + j0;
 #pragma unroll
                 for (int u = 0; u < kPairUnroll; ++u) {
-                    const int j = j0 + u * kSegWaves;
-                    cj[u] = lbox[j < K ? j : 0];
-                    aj[u] = larea[j < K ? j : 0];
+                    cj[u] = cb[u * kSegWaves];
+                    aj[u] = ab[u * kSegWaves];
                 }
 #pragma unroll
                 for (int u = 0; u < kPairUnroll; ++u) lo0[u] = vmax(ci.x, cj[u].x);
@@ -1248,7 +1251,6 @@ void k_segment_nms(SegArgs s)
                 for (int u = 0; u < kPairUnroll; ++u) uni[u] = ai + aj[u] - inter[u];
 #pragma unroll
                 for (int u = 0; u < kPairUnroll; ++u) {
-                    const int j = j0 + u * kSegWaves;
                     const bool yes = inter[u] > thr.hi * uni[u];
                     const bool no = inter[u] < thr.lo * uni[u];
                     // a union above 1e30 needs no guard: the bands then decide "no", which
@@ -1256,7 +1258,6 @@ void k_segment_nms(SegArgs s)
                     int v = (thr.fast & (uni[u] > 1e-30f) & (yes | no)) ? (yes ? 1 : 0) : 2;
                     if (MODE == YP_MODE_REFERENCE)
                         v = ((ai <= 0.0f) | (aj[u] <= 0.0f)) ? ((0.0f > thr.thr) ? 1 : 0) : v;
-                    v = ((i < j) && (j < K)) ? v : 0;
                     verdict[u] = v;
                     undecided |= v;
                 }
@@ -1271,8 +1272,10 @@ void k_segment_nms(SegArgs s)
                 }
 #pragma unroll
                 for (int u = 0; u < kPairUnroll; ++u) {
-                    const int j = j0 + u * kSegWaves;
-                    const u64 word = __ballot(verdict[u] == 1);
+                    const int j = j0 + u * kSegWaves;      // wave-uniform
+                    const int before = j - (w << 6);       // rows of this word that precede column j
+                    const u64 rows = before >= 64 ? ~0ull : lanes_below(before);
+                    const u64 word = __ballot(verdict[u] == 1) & rows;
                     if (lane == 0 && j < K) cw[j] = word;
                 }
             }
