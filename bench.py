@@ -77,6 +77,33 @@ def cpu_baseline(cpu_heads, inp_dim, conf, nms, budget_s=10.0):
                       "single thread" % (sample, reps, el)}
 
 
+def side_workload(args):
+    """The grid codec / training kernels (tools/bench_*.py) with their CPU baseline legs: the
+    restatements under oracle/ timed on the host, handed to the tools as plain callables."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    if args.workload == "grid_codec":
+        import bench_grid_codec as tool
+
+        def cpu(labels, anchors):
+            from oracle import np_oracle as npo
+            t0 = time.perf_counter()
+            grids = [npo.create_true_box_grid(y, anchors)[0] for y in labels]
+            t1 = time.perf_counter()
+            for g in grids:
+                npo.decode_true_box_grid(g, anchors)
+            return t1 - t0, time.perf_counter() - t1
+    else:
+        import bench_train_kernels as tool
+
+        def cpu(pred, grid, anchors):
+            from oracle import torch_ref
+            t0 = time.perf_counter()
+            p = pred.clone().requires_grad_(True)
+            torch_ref.loss_custom(p, grid, 13, 13, 5, 5, anchors)[0].backward()
+            return time.perf_counter() - t0
+    tool.run(None if args.no_cpu_baseline else cpu)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,9 +113,14 @@ def main():
     ap.add_argument("--clustered", action="store_true",
                     help="overlapping boxes around object centres instead of i.i.d. boxes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="detect", choices=["detect", "grid_codec", "train_kernels"],
+                    help="detect = the headline path (default); the others time the label-side and "
+                         "training-side kernels and print one JSON line per kernel")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="independent batches in flight (engines x HIP streams); 1 = latency mode")
     args = ap.parse_args()
+    if args.workload != "detect":
+        return side_workload(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

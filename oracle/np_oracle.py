@@ -7,7 +7,12 @@ few ulp (tests use 1e-5 relative), while the NMS routines, which use only + - * 
 comparisons, agree exactly when fed identical boxes.
 
 Mode R follows /root/reference/detect_net.py:152-183 (decode) and :90-146 (filter/NMS);
-Mode N follows the YOLOv3 tutorial semantics (not present in the reference).
+Mode N follows the YOLOv3 tutorial semantics (not present in the reference); the ground-truth
+grid codec at the bottom follows create_dataset.py:47-115 and :294-328.
+
+PARITY UNPINNED: the reference holds no test, fixture or golden vector for any of these
+functions and cannot be run here (TensorFlow is absent); the restatements are anchored by
+hand-computed known answers and by each other.
 """
 import numpy as np
 

@@ -1,7 +1,7 @@
-"""Times the ground-truth grid codec kernels (encode, decode) on one GPU and the numpy oracle
-beside them; prints one JSON line per kernel.
+"""Times the ground-truth grid codec kernels (encode, decode) on one GPU; prints one JSON line per
+kernel.  Run it through bench.py, which supplies the CPU baseline leg:
 
-    python tools/bench_grid_codec.py [--batch 4096] [--objects 32] [--iters 50]
+    python bench.py --workload grid_codec
 
 Algorithmic bytes: encode writes the whole grid and mask (slots*(5+2)*4 B per image) and
 reads 40 B per object; decode reads the grid once (slots*20 B) and writes 36 B per occupied
@@ -11,7 +11,6 @@ import importlib
 import json
 import os
 import sys
-import time
 
 import numpy as np
 import torch
@@ -21,13 +20,15 @@ sys.path.insert(0, ROOT)
 yp = importlib.import_module("2d_object_detection_amd")
 
 
-def main():
+def run(cpu_baseline=None, argv=None):
+    """cpu_baseline(labels_per_image, anchors) -> (encode_seconds, decode_seconds) on the host,
+    or None to leave the CPU leg out."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--objects", type=int, default=32)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--cpu-images", type=int, default=64)
-    a = ap.parse_args()
+    a = ap.parse_args(argv or [])
     rs = np.random.RandomState(0)
     B, n = a.batch, a.objects
     y = np.stack([rs.uniform(0, 1920, B * n), rs.uniform(0, 1280, B * n), rs.uniform(8, 1200, B * n),
@@ -57,17 +58,11 @@ def main():
     dec_ms = timed(lambda: cd.decode_true_box_grids_device(grid))
     enc_bytes = B * slots * 28 + B * n * 40
     dec_bytes = B * slots * 20 + occupied * 36
-    from oracle import np_oracle as npo
     anchors = np.asarray(yp.params.YOLO_ANCHORS)
     m = min(a.cpu_images, B)
-    t0 = time.perf_counter()
-    grids = [npo.create_true_box_grid(y[b * n:(b + 1) * n], anchors)[0] for b in range(m)]
-    t1 = time.perf_counter()
-    for g in grids:
-        npo.decode_true_box_grid(g, anchors)
-    t2 = time.perf_counter()
-    for name, ms, nbytes, cpu_s in (("grid_encode", enc_ms, enc_bytes, t1 - t0),
-                                    ("grid_decode", dec_ms, dec_bytes, t2 - t1)):
+    cpu = cpu_baseline([y[b * n:(b + 1) * n] for b in range(m)], anchors) if cpu_baseline else (None, None)
+    for name, ms, nbytes, cpu_s in (("grid_encode", enc_ms, enc_bytes, cpu[0]),
+                                    ("grid_decode", dec_ms, dec_bytes, cpu[1])):
         print(json.dumps({
             "metric": name + "_images_per_sec", "value": round(B / (ms * 1e-3), 1), "unit": "images/s",
             "ms_per_call": round(ms, 5), "dtype": "f64" if name == "grid_encode" else "f32",
@@ -77,9 +72,10 @@ def main():
                          "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 8e12, 4),
                          "algorithmic_bytes": nbytes,
                          "note": "includes the host wrapper (allocation + launch) of each call"},
-            "cpu_baseline": {"value": round(m / cpu_s, 1), "unit": "images/s", "cores": 1, "kind": "port",
-                             "sample": "%d images through the numpy oracle" % m}}))
+            "cpu_baseline": None if cpu_s is None else {
+                "value": round(m / cpu_s, 1), "unit": "images/s", "cores": 1, "kind": "port",
+                "sample": "%d images through the numpy restatement" % m}}))
 
 
 if __name__ == "__main__":
-    main()
+    run(argv=sys.argv[1:])

@@ -1,8 +1,8 @@
 """Times the fused loss_custom kernel (value + gradient) and the decode backward kernel on one
-GPU, next to the same loss composed from torch ops on the GPU and the torch restatement on the
-CPU; prints one JSON line per kernel.
+GPU, next to the same loss composed from torch ops on the GPU; prints one JSON line per kernel.
+Run it through bench.py, which supplies the CPU baseline leg:
 
-    python tools/bench_train_kernels.py [--batch 4096] [--iters 50]
+    python bench.py --workload train_kernels
 
 Algorithmic bytes per (cell, anchor) slot: fused loss 4*(5+C) head + 20 target + 4*(5+C)
 gradient; decode backward 4*(5+C) head + 4*(5+C) upstream + 4*(5+C) gradient."""
@@ -11,7 +11,6 @@ import importlib
 import json
 import os
 import sys
-import time
 
 import numpy as np
 import torch
@@ -23,12 +22,14 @@ H = W = 13
 A = C = 5
 
 
-def main():
+def run(cpu_baseline=None, argv=None):
+    """cpu_baseline(pred_cpu, grid_cpu, anchors) -> seconds of one forward + backward of the loss
+    on the host, or None to leave the CPU leg out."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--cpu-images", type=int, default=256)
-    a = ap.parse_args()
+    a = ap.parse_args(argv or [])
     B = a.batch
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
@@ -61,8 +62,6 @@ def main():
         p = pred.detach().requires_grad_(True)
         torch.autograd.backward(yp.DetectNet.predict_transform(p), ups)
 
-    sys.path.insert(0, ROOT)
-    from oracle import torch_ref
     anchors = np.asarray(yp.params.YOLO_ANCHORS)
 
     def composed_gpu():
@@ -93,11 +92,7 @@ def main():
     slots = B * H * W * A
     V = 5 + C
     m = min(a.cpu_images, B)
-    pc, gc = pred[:m].cpu(), grid[:m].cpu()
-    t0 = time.perf_counter()
-    p = pc.clone().requires_grad_(True)
-    torch_ref.loss_custom(p, gc, H, W, A, C, anchors)[0].backward()
-    cpu_s = time.perf_counter() - t0
+    cpu_s = cpu_baseline(pred[:m].cpu(), grid[:m].cpu(), anchors) if cpu_baseline else None
     for name, ms, nbytes in (("loss_custom_value_and_grad", fused_ms, slots * (4 * V + 20 + 4 * V)),
                              ("predict_transform_forward_backward", back_ms, slots * (4 * V * 3 + 4 * V * 2))):
         print(json.dumps({
@@ -109,10 +104,10 @@ def main():
                          "algorithmic_bytes": nbytes,
                          "note": "whole autograd round trip of the wrapper, not only the kernel"},
             "same_loss_from_torch_ops_on_this_gpu_ms": round(comp_ms, 5),
-            "cpu_baseline": {"value": round(m / cpu_s, 1), "unit": "images/s",
-                             "cores": torch.get_num_threads(), "kind": "port",
-                             "sample": "%d images, torch restatement forward+backward" % m}}))
+            "cpu_baseline": None if cpu_s is None else {
+                "value": round(m / cpu_s, 1), "unit": "images/s", "cores": torch.get_num_threads(),
+                "kind": "port", "sample": "%d images, torch restatement forward+backward" % m}}))
 
 
 if __name__ == "__main__":
-    main()
+    run(argv=sys.argv[1:])
