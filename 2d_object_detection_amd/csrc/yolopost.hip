@@ -1052,7 +1052,16 @@ void k_segment_nms(SegArgs s)
     __shared__ unsigned int s_pairs;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int seg = blockIdx.x;
+    // Workgroups b and b + 8 share an XCD (and its L2): deal every XCD a contiguous run of
+    // segments, so that the classes of one image -- which all read that image's candidate
+    // arrays -- are fetched into one L2 instead of up to C of them.  (Speed only: any
+    // bijection of workgroups to segments is correct.)
+    int seg;
+    {
+        const int nblk = (int)gridDim.x, x = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+        const int per = nblk >> 3, rem = nblk & 7;
+        seg = x < rem ? x * (per + 1) + k : rem * (per + 1) + (x - rem) * per + k;
+    }
     const int b = s.per_class ? seg / s.C : seg;
     const int c = s.per_class ? seg - b * s.C : 0;
     const size_t ibase = (size_t)b * s.spi;
