@@ -4,7 +4,7 @@ Images are independent (the reference itself loops over them, detect_net.py:125)
 batch is split into contiguous slices, one per rank (one process per GPU); decode, filter
 and NMS run with no communication.  The only exchange is a final variable-length
 all-gather of detection rows: first one count per rank, then one padded all-gather sized to
-the largest count.  Payloads are KB..MB, i.e. latency-bound on xGMI, hence two
+the largest count (both as all_gather_into_tensor).  Payloads are KB..MB, i.e. latency-bound on xGMI, hence two
 collectives in total rather than one per image.  With the ``nccl`` backend (RCCL on ROCm)
 the tensors stay on the GPU; the ``gloo`` backend is used by the CPU tests of this
 index arithmetic.
@@ -37,18 +37,19 @@ def all_gather_rows(rows, count=None, group=None):
     n = min(n, rows.shape[0])
     dev = rows.device
     cnt = torch.tensor([n], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(counts, cnt, group=group)
-    counts = [int(c.item()) for c in counts]
-    width = rows.shape[1:]
+    all_cnt = torch.zeros((world,), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_cnt, cnt, group=group)
+    counts = [int(c) for c in all_cnt.tolist()]
+    width = tuple(rows.shape[1:])
     m = max(counts)
     if m == 0:
-        return rows.new_zeros((0,) + tuple(width)), counts
-    send = rows.new_zeros((m,) + tuple(width))
+        return rows.new_zeros((0,) + width), counts
+    send = rows.new_zeros((m,) + width)
     send[:n] = rows[:n]
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
-    return torch.cat([r[:c] for r, c in zip(recv, counts)], dim=0), counts
+    recv = rows.new_empty((world * m,) + width)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view((world, m) + width)
+    return torch.cat([recv[r, :c] for r, c in enumerate(counts)], dim=0), counts
 
 
 class PaddedRowGather:

@@ -8,8 +8,11 @@ libyolopost.so) over one batch of synthetic raw detection heads that are already
 in HBM.  At N=1 the default workload is BASELINE.json's configs[1]: batch 64 at 416x416,
 three YOLOv3 heads x 3 anchors, 5 classes, conf 0.5 / NMS 0.4.  With N>1 (launched by
 torch.distributed.run, one rank per GPU) every rank processes its own batch of the same size
-(weak scaling) and the ranks exchange their variable-length detection lists with one
-fixed-capacity RCCL all-gather per step, double-buffered so it overlaps the next step.
+(weak scaling).  Images are independent, so a step needs no collective; the ranks exchange
+their variable-length detection lists with one RCCL all-gather at the end (--exchange final,
+the default) or after every step (--exchange every-step, overlapped with the next steps; at
+4 M images/s per GPU that is 97 GB/s of rows per rank to replicate everywhere, more than
+xGMI carries, so this mode is communication-bound and is reported next to the headline).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the front kernel (decode + filter + compaction), algorithmic bytes
@@ -113,6 +116,8 @@ def main():
     ap.add_argument("--clustered", action="store_true",
                     help="overlapping boxes around object centres instead of i.i.d. boxes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="final", choices=["final", "every-step"],
+                    help="N > 1: when the ranks exchange detection rows (see timed_run)")
     ap.add_argument("--workload", default="detect", choices=["detect", "grid_codec", "train_kernels"],
                     help="detect = the headline path (default); the others time the label-side and "
                          "training-side kernels and print one JSON line per kernel")
@@ -148,77 +153,111 @@ def main():
     rows_per_image = syn.anchors_per_image(inp_dim if isinstance(inp_dim, int) else tuple(inp_dim))
 
     # n_eng engines (own workspace and output buffers), each on its own HIP stream: consecutive
-    # batches are independent, so the decode of batch i+1 overlaps the NMS of batch i.  With ranks
-    # exchanging results, each engine writes straight into the payload of its gather buffer.
+    # batches are independent, so the decode of batch i+1 overlaps the NMS of batch i.
     n_eng = max(1, args.in_flight)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_eng)]
-    gathers, engines = [], []
-
-    def build(gather_cap):
-        gathers.clear()
-        engines.clear()
-        for _ in range(n_eng):
-            if world > 1:
-                g = dsb.PaddedRowGather(gather_cap, 8, dev)     # rows of 32 B
-                gathers.append(g)
-                engines.append(util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
-                                               batch_offset=rank * batch, out=g.rows))
-            else:
-                engines.append(util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev))
-
-    gather_cap = batch * 2048
-    build(gather_cap)
-    if world > 1:
-        # size the fixed-capacity exchange from one real batch: largest per-rank detection
-        # count over all ranks + 25 %, so the collective moves little more than the payload
-        _, cnt = engines[0].run(heads)
-        torch.cuda.synchronize()
-        cmax = cnt.to(torch.int64).clone()
-        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
-        gather_cap = max(1024, -(-int(cmax.item()) * 5 // 4 // 1024) * 1024)
-        build(gather_cap)
-    pending = [None] * n_eng
-    torch.cuda.synchronize()
-
-    def step(i):
-        k = i % n_eng
-        if world == 1:
-            engines[k].run(heads, streams[k])
-            return
-        with torch.cuda.stream(streams[k]):
-            if pending[k] is not None:
-                pending[k].wait()                # stream-level wait: buffer k is free again
-                pending[k] = None
-            _, count = engines[k].run(heads, streams[k])
-            pending[k] = gathers[k].gather(count, async_op=True)
-
-    def drain():
-        for k in range(n_eng):
-            if pending[k] is not None:
-                with torch.cuda.stream(streams[k]):
-                    pending[k].wait()
-                pending[k] = None
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    t_enqueued = time.perf_counter() - t0
-    drain()
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed_run(exchange, steps, warmup):
+        """K steps of the path on this rank's batches.  exchange (N > 1 only):
+        "final"      detections stay sharded by image while the steps run; the ranks exchange the
+                     variable-length detection list of the last batch with one all-gather at the
+                     end of the timed region
+        "every-step" one fixed-capacity all-gather of every rank's rows after every step, enqueued
+                     behind the kernels and overlapped with the following steps"""
+        gathers, engines = [], []
+        per_step = world > 1 and exchange == "every-step"
+
+        def build(gather_cap):
+            gathers.clear()
+            engines.clear()
+            for _ in range(n_eng):
+                if per_step:   # the engine writes straight into the payload of its gather buffer
+                    g = dsb.PaddedRowGather(gather_cap, 8, dev)     # rows of 32 B
+                    gathers.append(g)
+                    engines.append(util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
+                                                   batch_offset=rank * batch, out=g.rows))
+                else:
+                    engines.append(util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
+                                                   batch_offset=rank * batch))
+
+        gather_cap = batch * 2048
+        build(gather_cap)
+        if per_step:
+            # size the fixed-capacity exchange from one real batch: largest per-rank detection
+            # count over all ranks + 25 %, so the collective moves little more than the payload
+            _, cnt = engines[0].run(heads)
+            torch.cuda.synchronize()
+            cmax = cnt.to(torch.int64).clone()
+            dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+            gather_cap = max(1024, -(-int(cmax.item()) * 5 // 4 // 1024) * 1024)
+            build(gather_cap)
+        pending = [None] * n_eng
+        last = [None]
+        torch.cuda.synchronize()
+
+        def step(i):
+            k = i % n_eng
+            if not per_step:
+                last[0] = engines[k].run(heads, streams[k])
+                return
+            with torch.cuda.stream(streams[k]):
+                if pending[k] is not None:
+                    pending[k].wait()                # stream-level wait: buffer k is free again
+                    pending[k] = None
+                _, count = engines[k].run(heads, streams[k])
+                pending[k] = gathers[k].gather(count, async_op=True)
+
+        def drain():
+            for k in range(n_eng):
+                if pending[k] is not None:
+                    with torch.cuda.stream(streams[k]):
+                        pending[k].wait()
+                    pending[k] = None
+
+        for i in range(warmup):
+            step(i)
+        drain()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        t_enqueued = time.perf_counter() - t0
+        drain()
+        info = {}
+        if world > 1 and not per_step:
+            torch.cuda.synchronize()
+            rows, count = last[0]
+            gathered, counts = dsb.all_gather_rows(rows, count)
+            info = {"gather_rows_last_step": counts, "gathered_rows": int(gathered.shape[0])}
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if per_step:
+            gathered, counts = gathers[(steps - 1) % n_eng].unpack()
+            assert len(counts) == world
+            info = {"gather_rows_capacity_per_rank": gather_cap, "gather_rows_last_step": counts,
+                    "gather_overflow": bool(max(counts) > gather_cap)}
+            dist.barrier()
+        return elapsed, t_enqueued, engines, info
+
+    elapsed, t_enqueued, engines, xinfo = timed_run(args.exchange, args.steps, args.warmup)
+    other = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # the other exchange mode on a shorter loop, reported next to the headline
+        other_mode = "every-step" if args.exchange == "final" else "final"
+        o_steps = max(10, min(args.steps, 60))
+        o_el, _, _, o_info = timed_run(other_mode, o_steps, min(args.warmup, 5))
+        other = {"exchange": other_mode, "steps": o_steps,
+                 "images_per_s": round(world * batch * o_steps / o_el, 1)}
+        other.update({k: v for k, v in o_info.items() if k != "gather_rows_last_step"})
 
     # per-kernel execution times: each launch carries its own start/stop HIP events on the launch
     # stream (separate pass so the event bookkeeping does not perturb the throughput above)
@@ -249,12 +288,6 @@ def main():
 
     surv, kept, pairs = engines[0].segment_stats()
     total_surv, total_kept = int(surv.sum()), int(kept.sum())
-    if world > 1:
-        drain()
-        gathered, counts = gathers[(args.steps - 1) % n_eng].unpack()
-        assert len(counts) == world
-        gather_overflow = max(counts) > gather_cap
-        dist.barrier()
 
     if rank == 0:
         n_anchors = batch * rows_per_image
@@ -288,8 +321,8 @@ def main():
                                    "NCHW f32" % (args.config, desc, NUM_CLASSES),
                        "batch_per_gpu": batch, "global_batch": batch * world,
                        "anchors_per_image": rows_per_image,
-                       "parallelism": "dp%d (images sharded, one fixed-capacity RCCL all-gather "
-                                      "of detection rows per step)" % world if world > 1 else "dp1",
+                       "parallelism": "dp%d (images sharded over the ranks, no collective inside a step)"
+                                      % world if world > 1 else "dp1",
                        "survivors_per_image": round(total_surv / batch, 1),
                        "kept_per_image": round(total_kept / batch, 1),
                        "batches_in_flight": n_eng,
@@ -311,9 +344,14 @@ def main():
                                                         / (nms_ms * 1e-3), 1)},
         }
         if world > 1:
-            out["config"]["gather_rows_capacity_per_rank"] = gather_cap
-            out["config"]["gather_rows_last_step"] = counts
-            out["config"]["gather_overflow"] = bool(gather_overflow)
+            out["config"]["exchange"] = (
+                "final: detections stay sharded by image during the steps; one variable-length RCCL "
+                "all-gather of the last batch's detection rows closes the timed region"
+                if args.exchange == "final" else
+                "every-step: one fixed-capacity RCCL all-gather of all ranks' detection rows per step, "
+                "overlapped with the following steps")
+            out["config"].update(xinfo)
+            out["config"]["other_exchange_mode"] = other
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cpu_heads, inp_dim, conf, nms)
         print(json.dumps(out), flush=True)
