@@ -351,8 +351,9 @@ template <int CS, int NA>
 __global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBuf cb, float conf,
                                                             float t_lo, float t_hi)
 {
-    extern __shared__ float s_stage[];
-    constexpr int kStride = 6 + CS;
+    extern __shared__ __align__(16) float s_stage[];
+    constexpr int kStride = (6 + CS + 3) & ~3;   // t0..t4, packed (anchor, cell), CS class logits;
+                                                 // padded so that a record is whole float4s
     constexpr int V = 5 + CS;
     static_assert(kFrontCells == 128, "two cells per lane");
     const int tile = blockIdx.x, b = blockIdx.y;
@@ -410,6 +411,19 @@ __global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBu
                 if (v != 4) load_channel(a, v);
         }
     }
+#ifdef YP_LOADONLY   // diagnostic build: how long the loads alone take (results are garbage)
+    {
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc += t[c][a][v];
+        if (lane == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = acc == 12345.678f ? 1 : 0;
+        return;
+    }
+#endif
 #ifdef YP_STAMPS
     if (lane == 0 && ha.dbg) {
         asm volatile("" ::"v"(t[0][0][4]), "v"(t[1][NA - 1][4]));
@@ -450,12 +464,18 @@ __global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBu
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 if (pass[c][a] && rk >= 0 && rk < kStageWin) {
-                    float *st = s_stage + rk * kStride;
+                    float rec[kStride];
 #pragma unroll
-                    for (int v = 0; v < 5; ++v) st[v] = t[c][a][v];
-                    reinterpret_cast<int *>(st)[5] = (a << 24) | (cell + c);
+                    for (int v = 0; v < 5; ++v) rec[v] = t[c][a][v];
+                    rec[5] = __int_as_float((a << 24) | (cell + c));
 #pragma unroll
-                    for (int j = 0; j < CS; ++j) st[6 + j] = t[c][a][5 + j];
+                    for (int j = 0; j < CS; ++j) rec[6 + j] = t[c][a][5 + j];
+#pragma unroll
+                    for (int j = 6 + CS; j < kStride; ++j) rec[j] = 0.0f;
+                    float4 *st = reinterpret_cast<float4 *>(s_stage + rk * kStride);
+#pragma unroll
+                    for (int q = 0; q < kStride / 4; ++q)
+                        st[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
                 }
                 rk += pass[c][a] ? 1 : 0;
             }
@@ -470,8 +490,16 @@ __global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBu
 #endif
         const int end = total < base + kStageWin ? total : base + kStageWin;
         for (int r = base + lane; r < end; r += 64) {
-            const float *st = s_stage + (r - base) * kStride;
-            const int packed = reinterpret_cast<const int *>(st)[5];
+            float st[kStride];
+            {
+                const float4 *src = reinterpret_cast<const float4 *>(s_stage + (r - base) * kStride);
+#pragma unroll
+                for (int q = 0; q < kStride / 4; ++q) {
+                    const float4 v4 = src[q];
+                    st[4 * q] = v4.x; st[4 * q + 1] = v4.y; st[4 * q + 2] = v4.z; st[4 * q + 3] = v4.w;
+                }
+            }
+            const int packed = __float_as_int(st[5]);
             const int sa = packed >> 24, scell = packed & 0xffffff;
             const int row = scell / g.gw, col = scell - row * g.gw;
             // all 5 + CS exponentials of the row in one staged evaluation (independent chains
@@ -1962,7 +1990,8 @@ int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params, f
         // benchmarking: the front stage is skipped (the workspace keeps the previous candidates)
     } else if (params->num_classes == 5 && all_three)
         YP_LAUNCH(0, (k_front_heads_v3_wave<5, 3>), grid, dim3(64),
-                  (size_t)kStageWin * (6 + 5) * sizeof(float), st, ha, cb, params->conf_thr, t_lo, t_hi);
+                  (size_t)kStageWin * ((6 + 5 + 3) & ~3) * sizeof(float), st, ha, cb, params->conf_thr, t_lo,
+                  t_hi);
     else if (params->num_classes == 5)
         YP_LAUNCH(0, k_front_heads_v3<5>, grid, block, (size_t)ts * (6 + 5) * sizeof(float), st, ha, cb,
                   params->conf_thr, t_lo, t_hi);
