@@ -684,6 +684,63 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr keys, int n_pad)
     }
 }
 
+// Bitonic sort of exactly kSegThreads * E keys with E keys per thread held in registers
+// (thread t owns positions t*E .. t*E+E-1).  Compare-exchange partners at distance j are in the
+// same thread for j < E, in another lane of the wave for j < 64*E (xor-shuffles, no barrier) and
+// only beyond that in another wave, where the pass goes through `keys` (LDS or global memory)
+// with two barriers.  For 2048 keys that is 6 passes through memory instead of 66.
+template <int E, class KeyPtr>
+__device__ __forceinline__ void bitonic_sort_wide(KeyPtr keys, int n_pad)
+{
+    const int t = threadIdx.x, lane = t & 63;
+    u64 v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) v[r] = keys[t * E + r];
+    for (int k = 2; k <= n_pad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64 * E) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) keys[t * E + r] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const int idx = t * E + r;
+                    const u64 y = keys[idx ^ j];
+                    const bool keep_min = ((idx & j) == 0) == ((idx & k) == 0);
+                    v[r] = (keep_min == (v[r] < y)) ? v[r] : y;
+                }
+                __syncthreads();
+            } else if (j >= E) {
+                const int dl = j / E;   // partner lane = lane ^ dl, same register index
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const int idx = t * E + r;
+                    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v[r], dl, 64);
+                    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v[r] >> 32), dl, 64);
+                    const u64 y = ((u64)hi << 32) | lo;
+                    const bool keep_min = ((lane & dl) == 0) == ((idx & k) == 0);
+                    v[r] = (keep_min == (v[r] < y)) ? v[r] : y;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    if ((r & j) == 0) {   // (j < E: both of the pair are this thread's)
+                        const int idx = t * E + r;
+                        const u64 a = v[r], b = v[r | j];
+                        const bool up = (idx & k) == 0;
+                        const bool swap = (a > b) == up;
+                        v[r] = swap ? b : a;
+                        v[r | j] = swap ? a : b;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < E; ++r) keys[t * E + r] = v[r];
+    __syncthreads();
+}
+
 // Rank sort of K <= kSmallCap distinct keys: element e counts the keys below it and lands
 // at that position.  `in` is padded with ~0 up to a multiple of 8 keys.  When K is small,
 // S = 2^k threads share one element (each counts a slice of the keys, combined with
@@ -1373,7 +1430,9 @@ void k_segment_nms(SegArgs s)
             else gdst[i] = ~0ull;
         }
         __syncthreads();
-        if (in_lds) bitonic_sort(keys_in, n_pad);
+        if (in_lds && n_pad == 2 * kSegThreads) bitonic_sort_wide<2>(keys_in, n_pad);
+        else if (in_lds && n_pad == 4 * kSegThreads) bitonic_sort_wide<4>(keys_in, n_pad);
+        else if (in_lds) bitonic_sort(keys_in, n_pad);
         else bitonic_sort(gdst, n_pad);
         STAMP(3);
         float4 *gbox = s.sbox + reg;
