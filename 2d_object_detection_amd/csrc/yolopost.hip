@@ -348,7 +348,8 @@ __global__ void k_front_heads_v3(HeadsArgs ha, CandBuf cb, float conf, float t_l
 // and read by the same wave -- so the kernel has no barrier at all and a quarter of the
 // waves of the generic kernel above.  Same slots, same results.
 template <int CS, int NA>
-__global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBuf cb, float conf,
+__global__ __launch_bounds__(64)
+void k_front_heads_v3_wave(HeadsArgs ha, CandBuf cb, float conf,
                                                             float t_lo, float t_hi)
 {
     extern __shared__ __align__(16) float s_stage[];
@@ -502,28 +503,44 @@ __global__ __launch_bounds__(64) void k_front_heads_v3_wave(HeadsArgs ha, CandBu
             const int packed = __float_as_int(st[5]);
             const int sa = packed >> 24, scell = packed & 0xffffff;
             const int row = scell / g.gw, col = scell - row * g.gw;
-            // all 5 + CS exponentials of the row in one staged evaluation (independent chains
-            // interleaved); sigmoid(x) = 1 / (1 + exp(-x)) as in yp_sigmoid
-            float arg[V], e[V];
+            // Class score = largest sigmoid, class id = its first index.  The sigmoid is monotone
+            // and strictly separates arguments kYpGap apart (yp_math.h), so when no other logit
+            // lies within kYpGap below the largest one, one sigmoid decides; otherwise (rare) all
+            // CS are evaluated as written in the reference.
+            float xm = st[6];
+            int bi = 0;
+#pragma unroll
+            for (int j = 1; j < CS; ++j)
+                if (st[6 + j] > xm) { xm = st[6 + j]; bi = j; }
+            const float gap_lo = xm - kYpGap;
+            bool decided = (xm >= kYpGapLo) && (xm <= kYpGapHi);
+#pragma unroll
+            for (int j = 0; j < CS; ++j) decided = decided && !((st[6 + j] > gap_lo) && (st[6 + j] != xm));
+            // the box, objectness and top class exponentials in one staged evaluation
+            // (independent chains interleaved); sigmoid(x) = 1 / (1 + exp(-x)) as in yp_sigmoid
+            float arg[6], e[6];
             arg[0] = -st[0];
             arg[1] = -st[1];
             arg[2] = st[2];
             arg[3] = st[3];
             arg[4] = -st[4];
-#pragma unroll
-            for (int j = 0; j < CS; ++j) arg[5 + j] = -st[6 + j];
-            yp_exp_staged<V>(arg, e);
+            arg[5] = -xm;
+            yp_exp_staged<6>(arg, e);
             const float obj = 1.0f / (1.0f + e[4]);
             const float cx = (1.0f / (1.0f + e[0]) + (float)col) * g.sx;
             const float cy = (1.0f / (1.0f + e[1]) + (float)row) * g.sy;
             const float w = (e[2] * g.anc[2 * sa + 0]) * g.sx;
             const float hgt = (e[3] * g.anc[2 * sa + 1]) * g.sy;
             float best = 1.0f / (1.0f + e[5]);
-            int bi = 0;
-#pragma unroll
-            for (int j = 1; j < CS; ++j) {
-                const float sc = 1.0f / (1.0f + e[5 + j]);
-                if (sc > best) { best = sc; bi = j; }
+            if (!decided) {   // (a rolled loop over the staged record: this path must stay small)
+                const float *lg = s_stage + (r - base) * kStride + 6;
+                best = yp_sigmoid(lg[0]);
+                bi = 0;
+#pragma unroll 1
+                for (int j = 1; j < CS; ++j) {
+                    const float sc = yp_sigmoid(lg[j]);
+                    if (sc > best) { best = sc; bi = j; }
+                }
             }
             const float hw = w * 0.5f, hh = hgt * 0.5f;
             YpBox bx = {cx - hw, cy - hh, cx + hw, cy + hh};

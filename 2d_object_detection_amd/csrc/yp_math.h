@@ -54,6 +54,17 @@ YP_HD float yp_exp(float x)
 
 YP_HD float yp_sigmoid(float x) { return 1.0f / (1.0f + yp_exp(-x)); }
 
+// Two properties of yp_sigmoid that hold for EVERY binary32 argument and are checked
+// exhaustively by tests/test_sigmoid_order.py (all 2.2e9 floats of [-104, 89]; outside that
+// range the function is constant 0 or 1):
+//   (1) it is monotone non-decreasing;
+//   (2) for x in [kYpGapLo, kYpGapHi]:  yp_sigmoid(fl(x - kYpGap)) < yp_sigmoid(x).
+// Together they let a kernel find "the first index of the largest sigmoid" from the raw values:
+// with xm the largest argument (first index among equals), any argument <= fl(xm - kYpGap) has
+// a strictly smaller sigmoid, so if no other argument lies in (fl(xm - kYpGap), xm) the answer
+// is that index and yp_sigmoid(xm), computed once.
+constexpr float kYpGap = 1e-3f, kYpGapLo = -80.0f, kYpGapHi = 8.0f;
+
 // yp_exp of N independent arguments, written stage by stage so that neighbouring instructions
 // belong to different arguments (a single wave then issues back to back instead of waiting
 // for each dependent result).  Every element goes through exactly the operations of yp_exp,
