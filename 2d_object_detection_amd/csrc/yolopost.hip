@@ -383,10 +383,13 @@ void k_front_heads_v3_wave(HeadsArgs ha, CandBuf cb, float conf,
     const bool wide = ((reinterpret_cast<uintptr_t>(g.data) & 7) == 0) && ((cells & 1) == 0) &&
                       (cell0 + kFrontCells <= cells);
     if (wide) {
+        // (loaded as one 64-bit integer: as two floats the optimiser folds this branch and the
+        // other one into a single set of 4-byte loads with selected per-lane 64-bit addresses,
+        // which costs 120 registers)
         auto load_channel = [&](int a, int v) {
-            const float2 q = reinterpret_cast<const float2 *>(img + (size_t)(a * V + v) * cells)[lane];
-            t[0][a][v] = q.x;
-            t[1][a][v] = q.y;
+            const u64 q = reinterpret_cast<const u64 *>(img + (size_t)(a * V + v) * cells)[lane];
+            t[0][a][v] = __uint_as_float((unsigned)q);
+            t[1][a][v] = __uint_as_float((unsigned)(q >> 32));
         };
 #pragma unroll
         for (int a = 0; a < NA; ++a) load_channel(a, 4);
