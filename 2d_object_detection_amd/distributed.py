@@ -27,25 +27,35 @@ def all_gather_rows(rows, count=None, group=None):
     """Variable-length all-gather along dim 0.
 
     ``rows`` is this rank's (n_r, W) tensor (or a (cap, W) buffer of which the first
-    ``count`` rows are valid; ``count`` may be an int or a one-element tensor).  Returns
+    ``count`` rows are valid; ``count`` may be an int or a one-element tensor -- a tensor on
+    ``rows``' device is used where it is, without a host round trip).  Returns
     (gathered (sum n_r, W) ordered by rank, counts list).  Every rank gets the same
-    result."""
+    result.  Cost: two collectives and one host synchronisation (the counts, which size the
+    second collective); a buffer with spare capacity is sent from where it is."""
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
     world = dist.get_world_size(group)
-    n = rows.shape[0] if count is None else int(count)
-    n = min(n, rows.shape[0])
+    rank = dist.get_rank(group)
     dev = rows.device
-    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
-    all_cnt = torch.zeros((world,), dtype=torch.int64, device=dev)
+    cap = rows.shape[0]
+    if torch.is_tensor(count) and count.device == dev:
+        cnt = count.reshape(1).to(torch.int64).clamp(max=cap)
+    else:
+        n = cap if count is None else min(int(count), cap)
+        cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+    all_cnt = torch.empty((world,), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(all_cnt, cnt, group=group)
     counts = [int(c) for c in all_cnt.tolist()]
+    n = counts[rank]
     width = tuple(rows.shape[1:])
     m = max(counts)
     if m == 0:
         return rows.new_zeros((0,) + width), counts
-    send = rows.new_zeros((m,) + width)
-    send[:n] = rows[:n]
+    if cap >= m and rows.is_contiguous():
+        send = rows[:m]            # rows past n are padding, stripped below
+    else:
+        send = rows.new_zeros((m,) + width)
+        send[:n] = rows[:n]
     recv = rows.new_empty((world * m,) + width)
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view((world, m) + width)
@@ -115,5 +125,5 @@ class ShardedYoloV3Post:
         out, count = self.engine.run(local_heads)
         if self.world == 1:
             return out[:int(count.item())]
-        gathered, _ = all_gather_rows(out, int(count.item()), self.group)
+        gathered, _ = all_gather_rows(out, count, self.group)
         return gathered

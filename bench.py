@@ -10,9 +10,10 @@ three YOLOv3 heads x 3 anchors, 5 classes, conf 0.5 / NMS 0.4.  With N>1 (launch
 torch.distributed.run, one rank per GPU) every rank processes its own batch of the same size
 (weak scaling).  Images are independent, so a step needs no collective; the ranks exchange
 their variable-length detection lists with one RCCL all-gather at the end (--exchange final,
-the default) or after every step (--exchange every-step, overlapped with the next steps; at
-4 M images/s per GPU that is 97 GB/s of rows per rank to replicate everywhere, more than
-xGMI carries, so this mode is communication-bound and is reported next to the headline).
+the default; one untimed exchange beforehand warms the collective up) or, opt-in and
+experimental, after every step (--exchange every-step, overlapped with the next steps; at
+4 M images/s per GPU that is ~100 GB/s of rows per rank to replicate everywhere, more than
+xGMI carries, so that mode is communication-bound by construction).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the front kernel (decode + filter + compaction), algorithmic bytes
@@ -123,10 +124,16 @@ def main():
                          "training-side kernels and print one JSON line per kernel")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="independent batches in flight (engines x HIP streams); 1 = latency mode")
+    ap.add_argument("--also-other-exchange", action="store_true",
+                    help="N > 1: also time the exchange schedule that was not selected, on a short loop")
     args = ap.parse_args()
     if args.workload != "detect":
         return side_workload(args)
 
+    if os.environ.get("YP_BENCH_WATCHDOG"):
+        # diagnostic: after that many seconds dump every thread's Python stack and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["YP_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -222,6 +229,10 @@ def main():
         for i in range(warmup):
             step(i)
         drain()
+        if world > 1 and not per_step:
+            # the exchange is warmed up like the kernels: RCCL connects its channels on a
+            # collective's first use
+            dsb.all_gather_rows(torch.zeros((64, 8), device=dev), 64)
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -230,9 +241,9 @@ def main():
         drain()
         info = {}
         if world > 1 and not per_step:
-            torch.cuda.synchronize()
             rows, count = last[0]
-            gathered, counts = dsb.all_gather_rows(rows, count)
+            with torch.cuda.stream(streams[(steps - 1) % n_eng]):   # behind the last batch's kernels
+                gathered, counts = dsb.all_gather_rows(rows, count)
             info = {"gather_rows_last_step": counts, "gathered_rows": int(gathered.shape[0])}
         fence()
         elapsed = time.perf_counter() - t0
@@ -250,7 +261,7 @@ def main():
 
     elapsed, t_enqueued, engines, xinfo = timed_run(args.exchange, args.steps, args.warmup)
     other = None
-    if world > 1:
+    if world > 1 and args.also_other_exchange:
         # the other exchange mode on a shorter loop, reported next to the headline
         other_mode = "every-step" if args.exchange == "final" else "final"
         o_steps = max(10, min(args.steps, 60))
@@ -351,7 +362,8 @@ def main():
                 "every-step: one fixed-capacity RCCL all-gather of all ranks' detection rows per step, "
                 "overlapped with the following steps")
             out["config"].update(xinfo)
-            out["config"]["other_exchange_mode"] = other
+            if other is not None:
+                out["config"]["other_exchange_mode"] = other
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cpu_heads, inp_dim, conf, nms)
         print(json.dumps(out), flush=True)

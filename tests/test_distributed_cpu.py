@@ -41,6 +41,15 @@ def _worker(rank, world, port, q):
         ok = ok and c2 == [0] + [2] * (world - 1) and got2.shape[0] == 2 * (world - 1)
         got3, c3 = d.all_gather_rows(rows, 0)
         ok = ok and got3.shape == (0, 8) and c3 == [0] * world
+        # the count as a one-element tensor (used in place), and a count beyond the buffer
+        got5, c5 = d.all_gather_rows(rows, torch.tensor([n], dtype=torch.int32))
+        ok = ok and c5 == counts and torch.equal(got5, got)
+        got6, c6 = d.all_gather_rows(rows, torch.tensor([99], dtype=torch.int32))
+        ok = ok and c6 == [10] * world and got6.shape[0] == 10 * world
+        # a tensor that holds exactly its rows while another rank has more (send is padded)
+        mine = rows[:n].clone()
+        got7, c7 = d.all_gather_rows(mine)
+        ok = ok and c7 == counts and torch.equal(got7, got)
         # fixed-capacity gather: no host sync on the sending side, padding stripped on unpack
         pg = d.PaddedRowGather(6, 8, torch.device("cpu"))
         pg.rows[:n].copy_(rows[:n])
