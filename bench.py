@@ -28,6 +28,11 @@ import os
 import sys
 import time
 
+# HIP gives a process 4 hardware queues by default, one of which serves the null stream, so at
+# most 3 streams run concurrently; the path is fastest with 4 batches in flight on 4 queues of
+# their own.  Must be set before the HIP runtime initialises.  (YP_HW_QUEUES overrides.)
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("YP_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -145,8 +150,9 @@ def main():
     ap.add_argument("--workload", default="detect", choices=["detect", "grid_codec", "train_kernels"],
                     help="detect = the headline path (default); the others time the label-side and "
                          "training-side kernels and print one JSON line per kernel")
-    ap.add_argument("--in-flight", type=int, default=3,
-                    help="independent batches in flight (engines x HIP streams); 1 = latency mode")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="independent batches in flight (engines x HIP streams); 1 = latency mode; "
+                         "0 (default) = 3 or 4, whichever a short untimed probe finds faster here")
     ap.add_argument("--no-large-input", action="store_true",
                     help="skip the extra front-kernel measurement at the cfg3 shape")
     ap.add_argument("--also-other-exchange", action="store_true",
@@ -186,8 +192,25 @@ def main():
 
     # n_eng engines (own workspace and output buffers), each on its own HIP stream: consecutive
     # batches are independent, so the decode of batch i+1 overlaps the NMS of batch i.
-    n_eng = max(1, args.in_flight)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_eng)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(4, args.in_flight))]
+
+    def probe(n, steps=150):
+        """Local steps per second with n batches in flight (untimed calibration)."""
+        engs = [util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev) for _ in range(n)]
+        for i in range(30):
+            engs[i % n].run(heads, streams[i % n])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            engs[i % n].run(heads, streams[i % n])
+        torch.cuda.synchronize()
+        return steps / (time.perf_counter() - t0)
+
+    if args.in_flight > 0:
+        n_eng = args.in_flight
+    else:
+        rates = {n: probe(n) for n in (3, 4)}
+        n_eng = max(rates, key=rates.get)
 
     def fence():
         if world > 1:
@@ -362,6 +385,7 @@ def main():
                        "survivors_per_image": round(total_surv / batch, 1),
                        "kept_per_image": round(total_kept / batch, 1),
                        "batches_in_flight": n_eng,
+                       "hw_queues_requested": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "host_enqueue_us_per_step": round(t_enqueued / args.steps * 1e6, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_front_heads_v3 (decode+filter+compaction)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
