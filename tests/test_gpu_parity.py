@@ -527,3 +527,29 @@ def test_gpu_matches_committed_golden_vectors(pkg, dev):
     rows = torch.from_numpy(g["rows"]).to(dev)
     for name, thr in (("t04", 0.4), ("t13", 1.0 / 3.0), ("t05", 0.5), ("t10", 1.0)):
         assert np.array_equal(util.write_results(rows, 0.5, 3, thr).cpu().numpy(), g["det_" + name])
+
+
+# ------------------------------------------------------------------ batches in flight
+
+def test_v3_batches_in_flight_on_separate_streams_do_not_interfere(pkg, dev):
+    """Four engines (own workspace and outputs) on four streams, launched interleaved without
+    any synchronisation in between as the benchmark does: every engine's result equals the
+    one it produces alone, bit for bit."""
+    syn, util = pkg.synthetic, pkg.util
+    n = 4
+    inputs = [[h.to(dev) for h in syn.make_heads(8, 416, 5, seed=900 + k, clustered=(k == 2))]
+              for k in range(n)]
+    engines = [util.YoloV3Post(8, 416, 5, 0.5, 0.4, device=dev) for _ in range(n)]
+    alone = []
+    for k in range(n):
+        alone.append(engines[k].detect(inputs[k]).cpu().numpy().copy())
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    torch.cuda.synchronize()
+    for rep in range(25):
+        for k in range(n):
+            engines[k].run(inputs[k], streams[k])
+    torch.cuda.synchronize()
+    for k in range(n):
+        out, count = engines[k].out, int(engines[k].count.item())
+        assert count == alone[k].shape[0]
+        assert np.array_equal(out[:count].cpu().numpy(), alone[k]), k
