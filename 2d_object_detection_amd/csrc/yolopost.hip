@@ -1321,13 +1321,16 @@ void k_segment_nms(SegArgs s)
         // undecided lanes take the exact divide-and-compare.
         constexpr int kPairUnroll = YP_PAIR_UNROLL;
         const int wu = __builtin_amdgcn_readfirstlane(wave);
-        for (int w = 0; w < nwords; ++w) {
+        // mask words of the columns [cbeg, cend) against the row words [0, wend)
+        auto build_mask = [&](int cbeg, int cend, int wend) {
+        for (int w = 0; w < wend; ++w) {
             const int i = (w << 6) + lane;
             const float4 ci = lbox[i < K ? i : 0];
             const float ai = larea[i < K ? i : 0];
             const YpPrep pi = {ci.x, ci.y, ci.z, ci.w, ai};
             u64 *cw = cmask + (w * K - 32 * w * (w - 1)) - (w << 6);   // cw[j], j >= 64w
-            for (int j0 = (w << 6) + wu; j0 < K; j0 += kPairUnroll * kSegWaves) {
+            for (int j0 = ((w << 6) > cbeg ? (w << 6) : cbeg) + wu; j0 < cend;
+                 j0 += kPairUnroll * kSegWaves) {
                 int verdict[kPairUnroll];
                 int undecided = 0;
                 float4 cj[kPairUnroll];
@@ -1390,10 +1393,54 @@ void k_segment_nms(SegArgs s)
                     const int before = j - (w << 6);       // rows of this word that precede column j
                     const u64 rows = before >= 64 ? ~0ull : lanes_below(before);
                     const u64 word = __ballot(verdict[u] == 1) & rows;
-                    if (lane == 0 && j < K) cw[j] = word;
+                    if (lane == 0 && j < cend) cw[j] = word;
                 }
             }
         }
+        };
+        if (MODE == YP_MODE_REFERENCE && max_out < K) {
+            // An output cap can end the sweep long before the last candidate: build the mask one
+            // 64-column chunk at a time (against all earlier rows), sweep that chunk, and stop
+            // once max_out rows are kept.  Kept words of earlier chunks wait in LDS.
+            static_assert(sizeof(s_chunk.sup) >= kSmallWords * sizeof(u64), "kept words fit");
+            u64 *s_keptw = s_chunk.sup;           // written and read by wave 0 only
+            long long built = 0;
+            for (int cwd = 0; cwd < nwords; ++cwd) {
+                const int cbeg = cwd << 6, cend = cbeg + 64 < K ? cbeg + 64 : K;
+                build_mask(cbeg, cend, cwd + 1);
+                built += (long long)(cend - cbeg) * cbeg + (long long)(cend - cbeg) * (cend - cbeg - 1) / 2;
+                __syncthreads();
+                if (wave == 0) {
+                    const int j = cbeg + lane;
+                    const int jj = j < K ? j : cbeg;
+                    bool alive = j < K;
+                    for (int w = 0; w < cwd; ++w)
+                        alive = alive && (cmask[(w * K - 32 * w * (w - 1)) + jj - (w << 6)] & s_keptw[w]) == 0ull;
+                    const u64 mycol = (j < K) ? cmask[(cwd * K - 32 * cwd * (cwd - 1)) + jj - cbeg] : 0ull;
+                    u64 keep = __ballot(alive);
+                    for (int it = 0; it < 66; ++it) {
+                        const u64 nk = __ballot(alive && (mycol & keep) == 0ull);
+                        if (nk == keep) break;
+                        keep = nk;
+                    }
+                    const int room = max_out - nkept;
+                    if (__popcll(keep) > room)
+                        keep = __ballot(((keep >> lane) & 1ull) && __popcll(keep & lanes_below(lane)) < room);
+                    if ((keep >> lane) & 1ull)
+                        emit_kept(lslot, nkept + __popcll(keep & lanes_below(lane)), j,
+                                  s.cand_box[ibase + lslot[j]]);
+                    nkept += __popcll(keep);
+                    if (lane == 0) {
+                        s_keptw[cwd] = keep;
+                        s_cnt[3] = nkept;
+                    }
+                }
+                __syncthreads();
+                if (s_cnt[3] >= max_out) break;
+            }
+            pairs = tid == 0 ? (unsigned int)built : 0u;
+        } else {
+        build_mask(0, K, nwords);
         pairs = tid == 0 ? (unsigned int)((long long)K * (K - 1) / 2) : 0u;
         __syncthreads();
         STAMP(7);
@@ -1429,6 +1476,7 @@ void k_segment_nms(SegArgs s)
                     nkept += __popcll(keep);
                 }
             }
+        }
         }
         sslot_final = lslot;
     } else {

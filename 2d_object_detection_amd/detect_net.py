@@ -55,12 +55,19 @@ def _pack(per_image):
     return out
 
 
-def _unpad(boxes, scores, classes, index, counts):
-    """Padded device outputs -> the reference's four numpy arrays (one host copy each)."""
-    counts = counts.cpu().numpy()
-    boxes, scores = boxes.cpu().numpy(), scores.cpu().numpy()
-    classes, index = classes.cpu().numpy(), index.cpu().numpy()
-    B = counts.shape[0]
+def _unpad(outs):
+    """Padded device outputs -> the reference's four numpy arrays.  The six outputs are views of
+    one device buffer (see _alloc_outputs), so this is ONE device-to-host copy."""
+    B, mb = outs[0].shape[0], outs[0].shape[1]
+    n = B * mb
+    n4 = (n + 3) & ~3                                # as laid out by _alloc_outputs
+    host = outs[0]._yp_buffer.cpu().numpy()          # int32 words
+    boxes = host[0:4 * n].view(np.float32).reshape(B, mb, 4)
+    o = 4 * n
+    scores = host[o:o + n].view(np.float32).reshape(B, mb)
+    classes = host[o + n4:o + n4 + n].reshape(B, mb)
+    index = host[o + 2 * n4:o + 2 * n4 + n].reshape(B, mb)
+    counts = host[o + 3 * n4:o + 3 * n4 + B]
     pb = [boxes[b, :counts[b]].copy() for b in range(B)]
     ps = [scores[b, :counts[b]].copy() for b in range(B)]
     pc = [classes[b, :counts[b]].astype(np.int64) for b in range(B)]   # K.argmax is int64
@@ -69,13 +76,24 @@ def _unpad(boxes, scores, classes, index, counts):
 
 
 def _alloc_outputs(B, device):
+    """(boxes (B,mb,4) f32, scores (B,mb) f32, classes (B,mb) i32, index (B,mb) i32, counts (B) i32,
+    survivor counts (B) i32) as views of one int32 buffer: one allocation, and one copy when
+    the results go to the host.  mb is padded to a multiple of 4 rows' worth of words so that
+    every view starts 16-byte aligned."""
     mb = int(params.max_boxes)
-    return (torch.empty((B, mb, 4), dtype=torch.float32, device=device),
-            torch.empty((B, mb), dtype=torch.float32, device=device),
-            torch.empty((B, mb), dtype=torch.int32, device=device),
-            torch.empty((B, mb), dtype=torch.int32, device=device),
-            torch.empty((B,), dtype=torch.int32, device=device),
-            torch.empty((B,), dtype=torch.int32, device=device))
+    n = B * mb
+    n4 = (n + 3) & ~3                      # words per (B, mb) plane, 16-byte multiple
+    words = 4 * n + 3 * n4 + 2 * ((B + 3) & ~3)
+    buf = torch.empty((words,), dtype=torch.int32, device=device)
+    o = 0
+    boxes = buf[o:o + 4 * n].view(torch.float32).view(B, mb, 4); o += 4 * n
+    scores = buf[o:o + n].view(torch.float32).view(B, mb); o += n4
+    classes = buf[o:o + n].view(B, mb); o += n4
+    index = buf[o:o + n].view(B, mb); o += n4
+    counts = buf[o:o + B]; o += (B + 3) & ~3
+    surv = buf[o:o + B]
+    boxes._yp_buffer = buf
+    return boxes, scores, classes, index, counts, surv
 
 
 def _anchor_array(A):
@@ -199,7 +217,7 @@ class DetectNet():
                 _lib.stream_ptr(dev))
         _lib.check(rc, "yp_filter_boxes_reference")
         DetectNet.last_survivor_counts = outs[5]
-        return _unpad(*outs[:5])
+        return _unpad(outs)
 
     @staticmethod
     def detect_device(predictions):
@@ -230,4 +248,4 @@ class DetectNet():
     def detect(predictions):
         """filter_boxes(predict_transform(predictions)) in one fused pass, returned in the
         reference's numpy structure (what train.py:347-348 computes)."""
-        return _unpad(*DetectNet.detect_device(predictions)[:5])
+        return _unpad(DetectNet.detect_device(predictions))

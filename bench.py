@@ -113,6 +113,19 @@ def side_workload(args):
     """The grid codec / training kernels (tools/bench_*.py) with their CPU baseline legs: the
     restatements under oracle/ timed on the host, handed to the tools as plain callables."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
+    if args.workload == "reference":
+        import bench_reference_mode as tool
+
+        def cpu(pred):
+            import oracle
+            P = pkg.params
+            anchors = np.asarray(P.YOLO_ANCHORS, np.float32).reshape(-1, 2)
+            t0 = time.perf_counter()
+            oracle.r_detect(pred, P.grid_height, P.grid_width, P.num_anchors, P.num_classes, anchors,
+                            P.object_conf, P.nms_conf, P.max_boxes, P.im_height, P.im_width)
+            return time.perf_counter() - t0
+
+        return tool.run(cpu_baseline=None if args.no_cpu_baseline else cpu)
     if args.workload == "grid_codec":
         import bench_grid_codec as tool
 
@@ -147,8 +160,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="final", choices=["final", "every-step"],
                     help="N > 1: when the ranks exchange detection rows (see timed_run)")
-    ap.add_argument("--workload", default="detect", choices=["detect", "grid_codec", "train_kernels"],
-                    help="detect = the headline path (default); the others time the label-side and "
+    ap.add_argument("--workload", default="detect",
+                    choices=["detect", "reference", "grid_codec", "train_kernels"],
+                    help="detect = the headline path (default); reference = the reference's own 13x13 configuration; "
+                         "the others time the label-side and "
                          "training-side kernels and print one JSON line per kernel")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="independent batches in flight (engines x HIP streams); 1 = latency mode; "
