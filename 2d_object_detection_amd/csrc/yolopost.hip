@@ -38,7 +38,8 @@ constexpr int kFrontCells = 64 * kFrontGroups;
 constexpr int kStageWin = 128;    // survivors staged per round by the single-wave front kernel
 constexpr int kSegThreads = 512;  // threads per NMS workgroup (the kernel is only validated for 512)
 constexpr int kSegWaves = kSegThreads / 64;
-constexpr int kSortCap = 2048;    // largest segment sorted in LDS
+constexpr int kSortCap = 2048;    // largest segment whose keys are gathered straight into LDS
+constexpr int kBigSortCap = 4096; // largest segment sorted in LDS (gathered to memory first)
 constexpr int kSmallCap = 512;    // segments up to this size use the all-pairs LDS bitmask path
 constexpr int kSmallWords = kSmallCap / 64;
 // words of the triangular pairwise bitmask of a kSmallCap segment: sum_w (cap - 64 w)
@@ -1147,8 +1148,10 @@ void k_segment_nms(SegArgs s)
     // s_small: [0, 8(cap+8)) gathered keys, later the sorted slot ids and box areas;
     // [8(cap+8), 16(cap+8)) sorted keys; [16(cap+8), 32(cap+8)) the tile-count prefix during
     // the gather, later the sorted boxes.
-    __shared__ __align__(16) unsigned char s_raw[kRawBytes];
-    __shared__ __align__(16) unsigned char s_small[kSmallBytes];
+    // (one block, so that a segment of up to kBigSortCap keys can be sorted across both parts)
+    __shared__ __align__(16) unsigned char s_lds[kRawBytes + kSmallBytes];
+    static_assert(kRawBytes % 16 == 0 && kRawBytes + kSmallBytes >= kBigSortCap * 8, "layout");
+    unsigned char *s_raw = s_lds, *s_small = s_lds + kRawBytes;
     int *s_tpre = reinterpret_cast<int *>(s_small + 16 * (kSmallCap + 8));
     static_assert(kTileCap * 4 <= 16 * (kSmallCap + 8), "tile prefix must fit the box region");
     __shared__ ChunkShared s_chunk;
@@ -1208,37 +1211,49 @@ void k_segment_nms(SegArgs s)
     u64 *gk = s.gkeys + 2 * ibase;  // rebased to the segment's region below
     auto gather = [&](bool to_lds, u64 *gdst) {
         int lt = 0;
-        for (int q0 = 0; q0 < k_img; q0 += kSegThreads) {
-            const int q = q0 + tid;
-            bool mine = false, below = false;
-            u64 key = 0ull;
-            if (q < k_img) {
-                int lo = 0, hi = tpi;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    const int pm = pre_lds ? s_tpre[mid] : gpre[mid];
-                    if (pm <= q) lo = mid; else hi = mid;
+        constexpr int kPer = 2;   // candidates per thread and round: their loads overlap
+        for (int q0 = 0; q0 < k_img; q0 += kPer * kSegThreads) {
+            int slot[kPer], cl[kPer];
+            float kf[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int q = q0 + u * kSegThreads + tid;
+                slot[u] = -1;
+                kf[u] = 0.0f;
+                cl[u] = c;
+                if (q < k_img) {
+                    int lo = 0, hi = tpi;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        const int pm = pre_lds ? s_tpre[mid] : gpre[mid];
+                        if (pm <= q) lo = mid; else hi = mid;
+                    }
+                    slot[u] = lo * ts + (q - (pre_lds ? s_tpre[lo] : gpre[lo]));
+                    kf[u] = s.cand_key[ibase + slot[u]];
+                    if (s.per_class) cl[u] = s.cand_cls[ibase + slot[u]];
                 }
-                const int slot = lo * ts + (q - (pre_lds ? s_tpre[lo] : gpre[lo]));
-                const float kf = s.cand_key[ibase + slot];
-                const int cl = s.per_class ? s.cand_cls[ibase + slot] : c;
-                below = cl < c;
-                mine = cl == c;
-                key = ((u64)(~yp_float_order_bits(kf)) << 32) | (u64)(unsigned int)slot;
             }
-            lt += __popcll(__ballot(below));   // wave-uniform count
-            const u64 m = __ballot(mine);
-            if (m != 0ull) {
-                int basepos = 0;
-                if (lane == 0) basepos = atomicAdd(&s_cnt[1], __popcll(m));
-                basepos = __shfl(basepos, 0, 64);
-                if (mine) {
-                    const int pos = basepos + __popcll(m & lanes_below(lane));
-                    if (to_lds) {
-                        if (pos < kSortCap) keys_in[pos] = key;
-                        if (pos < kSmallCap) keys_small[pos] = key;
-                    } else {
-                        gdst[pos] = key;
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                if (q0 + u * kSegThreads >= k_img) break;   // uniform
+                const bool valid = slot[u] >= 0;
+                const bool below = valid && cl[u] < c;
+                const bool mine = valid && cl[u] == c;
+                const u64 key = ((u64)(~yp_float_order_bits(kf[u])) << 32) | (u64)(unsigned int)slot[u];
+                lt += __popcll(__ballot(below));   // wave-uniform count
+                const u64 m = __ballot(mine);
+                if (m != 0ull) {
+                    int basepos = 0;
+                    if (lane == 0) basepos = atomicAdd(&s_cnt[1], __popcll(m));
+                    basepos = __shfl(basepos, 0, 64);
+                    if (mine) {
+                        const int pos = basepos + __popcll(m & lanes_below(lane));
+                        if (to_lds) {
+                            if (pos < kSortCap) keys_in[pos] = key;
+                            if (pos < kSmallCap) keys_small[pos] = key;
+                        } else {
+                            gdst[pos] = key;
+                        }
                     }
                 }
             }
@@ -1498,16 +1513,23 @@ void k_segment_nms(SegArgs s)
             else gdst[i] = ~0ull;
         }
         __syncthreads();
+        // keys gathered to memory still sort in LDS when they fit the whole block (the tile
+        // prefix and everything else in it is dead by now)
+        const bool big_lds = !in_lds && n_pad <= kBigSortCap;
         if (in_lds && n_pad == 2 * kSegThreads) bitonic_sort_wide<2>(keys_in, n_pad);
         else if (in_lds && n_pad == 4 * kSegThreads) bitonic_sort_wide<4>(keys_in, n_pad);
         else if (in_lds) bitonic_sort(keys_in, n_pad);
-        else bitonic_sort(gdst, n_pad);
+        else if (big_lds) {
+            for (int i = tid; i < n_pad; i += kSegThreads) keys_in[i] = gdst[i];
+            __syncthreads();
+            bitonic_sort(keys_in, n_pad);
+        } else bitonic_sort(gdst, n_pad);
         STAMP(3);
         float4 *gbox = s.sbox + reg;
         int *gslot = s.sslot + reg;
         unsigned char *grem = s.removed + reg;
         for (int i = tid; i < K; i += kSegThreads) {
-            const int slot = (int)(unsigned int)((in_lds ? keys_in[i] : gdst[i]) & 0xffffffffull);
+            const int slot = (int)(unsigned int)((in_lds || big_lds ? keys_in[i] : gdst[i]) & 0xffffffffull);
             gslot[i] = slot;
             gbox[i] = s.cand_box[ibase + slot];
             grem[i] = 0;

@@ -195,7 +195,8 @@ def big_segment_rows(n, seed, span=1900.0, degenerate=False, offset=0.0):
 
 @pytest.mark.parametrize("n,seed,nms,degenerate,offset", [
     (1500, 1, 0.4, False, 0.0),       # pruned flushes, several waves' list parts
-    (3000, 2, 0.45, False, 0.0),      # beyond the LDS sort: global keys, many flushes
+    (3000, 2, 0.45, False, 0.0),      # keys gathered to memory, sorted in LDS; many flushes
+    (4700, 8, 0.4, False, 0.0),       # beyond the LDS sort: keys sorted in global memory
     (1400, 3, 0.4, True, 0.0),        # non-positive areas switch the pruning off
     (1300, 4, 0.0, False, 0.0),       # threshold 0: nothing may be skipped, everything suppresses
     (1300, 5, 1.0, False, 0.0),       # threshold 1: only identical boxes suppress
