@@ -1537,9 +1537,13 @@ void k_segment_nms(SegArgs s)
         __syncthreads();
         STAMP(4);
         sslot_final = gslot;
-        // ---- x-order of the candidates: counting sort by the box centre along the pruning
-        // axis into 256 buckets (LDS histogram; the order inside a bucket is whatever the
-        // atomics give, which only changes which lane owns which column, never a verdict).
+        // ---- x-order of the candidates: counting sort by (stripe, width class, position inside
+        // the stripe) of the box centre along the pruning axis into 8 x 32 buckets (LDS
+        // histogram; the order inside a bucket is whatever the atomics give, which only changes
+        // which lane owns which column, never a verdict).  Inside each of the 8 stripes -- about
+        // one per wave -- narrow, medium and wide boxes form runs of their own: a batch of 64
+        // neighbours then spans a band about as wide as its own boxes instead of as wide as the
+        // widest box around, and far fewer waiting rows reach it.
         // The sort keys are no longer needed, so their global region becomes the x-ordered
         // copy of the boxes and s_raw the histogram.
         constexpr int kXB = 256;
@@ -1550,10 +1554,12 @@ void k_segment_nms(SegArgs s)
         int *s_pos = reinterpret_cast<int *>(s_red + 2 * kSegWaves); // [kSegWaves] all areas > 0
         float4 *xraw = reinterpret_cast<float4 *>(gk + 2 * (size_t)region);
         int *xidx = s.xidx + reg;
+        float width = 0.0f;   // of the box axis_key looked at last, along the pruning axis
         auto axis_key = [&](const float4 &raw, bool &positive) {
             const YpBox bx = {raw.x, raw.y, raw.z, raw.w};
             const YpPrep pp = yp_prep<MODE>(bx);
             positive = pp.area > 0.0f;
+            width = MODE == YP_MODE_YOLOV3 ? pp.hi0 - pp.lo0 : pp.hi1 - pp.lo1;
             return MODE == YP_MODE_YOLOV3 ? pp.lo0 + pp.hi0 : pp.lo1 + pp.hi1;
         };
         {
@@ -1588,13 +1594,22 @@ void k_segment_nms(SegArgs s)
             kmax = vmax(kmax, s_red[kSegWaves + w]);
             allpos = allpos && s_pos[w] != 0;
         }
-        const float range = kmax - kmin;
-        const float scale = (range > 0.0f && range < 3.0e38f) ? (float)kXB / range : 0.0f;
-        auto bucket = [&](float key) {
+        const float range = kmax - kmin;   // of lo + hi, i.e. twice the spread of the centres
+        constexpr int kStripes = kSegWaves, kPerStripe = kXB / kStripes;
+        static_assert(kPerStripe == 32, "bins per stripe: 14 narrow + 10 medium + 8 wide");
+        const float scale = (range > 0.0f && range < 3.0e38f) ? (float)kStripes / range : 0.0f;
+        const float w_narrow = range * (1.0f / 96.0f), w_medium = range * (1.0f / 24.0f);
+        auto bucket = [&](float key) {     // uses the width axis_key left behind
             float t = (key - kmin) * scale;
-            t = t > 0.0f ? t : 0.0f;                       // also turns a NaN into bucket 0
-            t = t < (float)(kXB - 1) ? t : (float)(kXB - 1);
-            return (int)t;
+            t = t > 0.0f ? t : 0.0f;                       // also turns a NaN into stripe 0
+            t = t < (float)kStripes ? t : (float)kStripes;
+            int stripe = (int)t;
+            stripe = stripe < kStripes ? stripe : kStripes - 1;
+            float f = t - (float)stripe;                   // position inside the stripe, [0, 1]
+            f = f < 1.0f ? f : 0.999f;
+            const bool narrow = width <= w_narrow, medium = width <= w_medium;   // NaN: wide
+            const int first = narrow ? 0 : (medium ? 14 : 24), bins = narrow ? 14 : (medium ? 10 : 8);
+            return stripe * kPerStripe + first + (int)(f * (float)bins);
         };
         for (int i = tid; i < K; i += kSegThreads) {
             bool positive;
