@@ -808,9 +808,13 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l)
 // Kept rows of up to kPend chunks wait in LDS before one pass over the later columns applies
 // them all ("flush"); until then every new chunk is first tested against the waiting rows.
 #ifndef YP_PEND
-#define YP_PEND 2
+#define YP_PEND 4
 #endif
 constexpr int kPend = YP_PEND;
+#ifndef YP_PEND_LONG
+#define YP_PEND_LONG 8192
+#endif
+constexpr int kPendLongList = YP_PEND_LONG;   // segments above this use all kPend chunks of room
 
 // LDS scratch of the chunk loop.
 struct ChunkShared {
@@ -913,6 +917,8 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int nkept = 0;
     int npend = 0;   // kept rows waiting in sh.kprep (uniform over the workgroup)
+    // a flush walks every live column, so very long lists let more rows wait before one
+    const int pend_limit = K > kPendLongList ? (kPend - 1) * 64 : (kPend > 2 ? 64 : (kPend - 1) * 64);
     // the x-ordered list is split into one contiguous part per wave (whole batches of 64)
     const int per_wave = (((K + 63) >> 6) + kSegWaves - 1) / kSegWaves * 64;
     const int wbeg = wave * per_wave < K ? wave * per_wave : K;
@@ -1042,7 +1048,7 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
         // verdict; without `prune` every waiting row is walked.  Every wave owns one contiguous
         // part of the list for the whole loop; a removed column is flagged in `removed` for
         // the chunk loader and leaves the list.
-        if (npend > (kPend - 1) * 64 && r0 + 64 < K) {
+        if (npend > pend_limit && r0 + 64 < K) {
             const int nrw = (npend + 63) >> 6;   // words of waiting rows
             // this wave's part of the list is [wbeg, wbeg + wlen); survivors are written back
             // densely from wbeg on (never ahead of the read position), so the next flush finds
