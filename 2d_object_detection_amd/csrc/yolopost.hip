@@ -1408,13 +1408,19 @@ void k_segment_nms(SegArgs s)
                         }
                     }
                 }
+                // lane u stores the word of column u: one store instead of kPairUnroll
+                // single-lane ones
+                u64 mine = 0ull;
 #pragma unroll
                 for (int u = 0; u < kPairUnroll; ++u) {
-                    const int j = j0 + u * kSegWaves;      // wave-uniform
+                    const u64 word = __ballot(verdict[u] == 1);
+                    mine = lane == u ? word : mine;
+                }
+                {
+                    const int j = j0 + lane * kSegWaves;
                     const int before = j - (w << 6);       // rows of this word that precede column j
                     const u64 rows = before >= 64 ? ~0ull : lanes_below(before);
-                    const u64 word = __ballot(verdict[u] == 1) & rows;
-                    if (lane == 0 && j < cend) cw[j] = word;
+                    if (lane < kPairUnroll && j < cend) cw[j] = mine & rows;
                 }
             }
         }
