@@ -46,7 +46,6 @@ constexpr int kSmallWords = kSmallCap / 64;
 constexpr int kMaskWords = kSmallWords * kSmallCap - 32 * kSmallWords * (kSmallWords - 1);
 constexpr int kRawBytes = (kSortCap * 8 > kMaskWords * 8) ? kSortCap * 8 : kMaskWords * 8;
 constexpr int kSmallBytes = 32 * (kSmallCap + 8) + 16 * 32;   // + 32 boxes the pair loop may over-read
-constexpr int kTileCap = 2048;    // tile-count prefix held in LDS up to this many tiles
 
 // ------------------------------------------------------------------------ device structs
 
@@ -1152,14 +1151,11 @@ void k_segment_nms(SegArgs s)
     // s_raw: sort keys of segments above kSmallCap (bitonic sort, up to kSortCap keys); for
     // small segments the triangular pairwise suppression bitmask.
     // s_small: [0, 8(cap+8)) gathered keys, later the sorted slot ids and box areas;
-    // [8(cap+8), 16(cap+8)) sorted keys; [16(cap+8), 32(cap+8)) the tile-count prefix during
-    // the gather, later the sorted boxes.
+    // [8(cap+8), 16(cap+8)) sorted keys; [16(cap+8), 32(cap+8)) the sorted boxes.
     // (one block, so that a segment of up to kBigSortCap keys can be sorted across both parts)
     __shared__ __align__(16) unsigned char s_lds[kRawBytes + kSmallBytes];
     static_assert(kRawBytes % 16 == 0 && kRawBytes + kSmallBytes >= kBigSortCap * 8, "layout");
     unsigned char *s_raw = s_lds, *s_small = s_lds + kRawBytes;
-    int *s_tpre = reinterpret_cast<int *>(s_small + 16 * (kSmallCap + 8));
-    static_assert(kTileCap * 4 <= 16 * (kSmallCap + 8), "tile prefix must fit the box region");
     __shared__ ChunkShared s_chunk;
     __shared__ int s_cnt[4];   // [0] candidates of lower classes, [1] of this class
     __shared__ int s_scan[kSegWaves];
@@ -1182,85 +1178,88 @@ void k_segment_nms(SegArgs s)
     const int *tcount = s.tile_count + (size_t)b * s.tpi;
     int *gpre = s.tile_prefix + (size_t)b * s.tpi;
     const int tpi = s.tpi, ts = s.ts;
-    const bool pre_lds = tpi <= kTileCap;
 
     if (tid < 4) s_cnt[tid] = 0;
     if (tid == 0) s_pairs = 0u;
     STAMP(0);
 
-    // ---- exclusive prefix of the image's tile counts (LDS when it fits, else global)
-    int k_img = 0;
-    for (int base = 0; base < tpi; base += kSegThreads) {
-        const int v = (base + tid < tpi) ? tcount[base + tid] : 0;
-        const int incl = wave_inclusive_scan(v, lane);
-        if (lane == 63) s_scan[wave] = incl;
-        __syncthreads();
-        int woff = 0, total = 0;
-        for (int w = 0; w < kSegWaves; ++w) {
-            if (w < wave) woff += s_scan[w];
-            total += s_scan[w];
+    // ---- exclusive prefix of the image's tile counts: a kept row's position in the image's
+    // survivor list, which only the reference-mode output reports
+    if (MODE == YP_MODE_REFERENCE) {
+        int k_img = 0;
+        for (int base = 0; base < tpi; base += kSegThreads) {
+            const int v = (base + tid < tpi) ? tcount[base + tid] : 0;
+            const int incl = wave_inclusive_scan(v, lane);
+            if (lane == 63) s_scan[wave] = incl;
+            __syncthreads();
+            int woff = 0, total = 0;
+            for (int w = 0; w < kSegWaves; ++w) {
+                if (w < wave) woff += s_scan[w];
+                total += s_scan[w];
+            }
+            if (base + tid < tpi) gpre[base + tid] = k_img + woff + incl - v;
+            k_img += total;
+            __syncthreads();
         }
-        if (base + tid < tpi) {
-            const int e = k_img + woff + incl - v;
-            if (pre_lds) s_tpre[base + tid] = e;
-            if (!pre_lds || MODE == YP_MODE_REFERENCE) gpre[base + tid] = e;
-        }
-        k_img += total;
-        __syncthreads();
+    } else {
+        __syncthreads();   // s_cnt is cleared
     }
 
     STAMP(1);
-    // ---- gather: thread q takes the image's q-th candidate (binary search of its tile),
-    // keeps it if it belongs to this segment and appends its sort key
+    // ---- gather: a wave takes kGatherTiles tiles per round, lane r looks at candidate r of each
+    // (the tile's count and the candidate's key and class are requested together, so a round is
+    // one trip to memory; slots past the count hold stale values that are ignored), keeps the
+    // candidates of this segment and appends their sort keys in any order
     u64 *keys_in = reinterpret_cast<u64 *>(s_raw);
     u64 *keys_small = reinterpret_cast<u64 *>(s_small);
     u64 *gk = s.gkeys + 2 * ibase;  // rebased to the segment's region below
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     auto gather = [&](bool to_lds, u64 *gdst) {
         int lt = 0;
-        constexpr int kPer = 2;   // candidates per thread and round: their loads overlap
-        for (int q0 = 0; q0 < k_img; q0 += kPer * kSegThreads) {
-            int slot[kPer], cl[kPer];
-            float kf[kPer];
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                const int q = q0 + u * kSegThreads + tid;
-                slot[u] = -1;
-                kf[u] = 0.0f;
-                cl[u] = c;
-                if (q < k_img) {
-                    int lo = 0, hi = tpi;
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        const int pm = pre_lds ? s_tpre[mid] : gpre[mid];
-                        if (pm <= q) lo = mid; else hi = mid;
+        constexpr int kGatherTiles = 4;
+        auto take = [&](int slot, bool valid, float kf, int cl) {
+            const bool below = valid && cl < c;
+            const bool mine = valid && cl == c;
+            const u64 key = ((u64)(~yp_float_order_bits(kf)) << 32) | (u64)(unsigned int)slot;
+            lt += __popcll(__ballot(below));   // wave-uniform count
+            const u64 m = __ballot(mine);
+            if (m != 0ull) {
+                int basepos = 0;
+                if (lane == 0) basepos = atomicAdd(&s_cnt[1], __popcll(m));
+                basepos = __shfl(basepos, 0, 64);
+                if (mine) {
+                    const int pos = basepos + __popcll(m & lanes_below(lane));
+                    if (to_lds) {
+                        if (pos < kSortCap) keys_in[pos] = key;
+                        if (pos < kSmallCap) keys_small[pos] = key;
+                    } else {
+                        gdst[pos] = key;
                     }
-                    slot[u] = lo * ts + (q - (pre_lds ? s_tpre[lo] : gpre[lo]));
-                    kf[u] = s.cand_key[ibase + slot[u]];
-                    if (s.per_class) cl[u] = s.cand_cls[ibase + slot[u]];
                 }
             }
+        };
+        for (int t0 = wv * kGatherTiles; t0 < tpi; t0 += kSegWaves * kGatherTiles) {
+            int cnt[kGatherTiles], cl[kGatherTiles];
+            float kf[kGatherTiles];
 #pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                if (q0 + u * kSegThreads >= k_img) break;   // uniform
-                const bool valid = slot[u] >= 0;
-                const bool below = valid && cl[u] < c;
-                const bool mine = valid && cl[u] == c;
-                const u64 key = ((u64)(~yp_float_order_bits(kf[u])) << 32) | (u64)(unsigned int)slot[u];
-                lt += __popcll(__ballot(below));   // wave-uniform count
-                const u64 m = __ballot(mine);
-                if (m != 0ull) {
-                    int basepos = 0;
-                    if (lane == 0) basepos = atomicAdd(&s_cnt[1], __popcll(m));
-                    basepos = __shfl(basepos, 0, 64);
-                    if (mine) {
-                        const int pos = basepos + __popcll(m & lanes_below(lane));
-                        if (to_lds) {
-                            if (pos < kSortCap) keys_in[pos] = key;
-                            if (pos < kSmallCap) keys_small[pos] = key;
-                        } else {
-                            gdst[pos] = key;
-                        }
-                    }
+            for (int u = 0; u < kGatherTiles; ++u) {
+                const int tile = t0 + u < tpi ? t0 + u : tpi - 1;
+                const int slot = tile * ts + lane;
+                cnt[u] = t0 + u < tpi ? tcount[tile] : 0;
+                kf[u] = s.cand_key[ibase + slot];
+                cl[u] = s.per_class ? s.cand_cls[ibase + slot] : c;
+            }
+#pragma unroll
+            for (int u = 0; u < kGatherTiles; ++u)
+                take((t0 + u) * ts + lane, lane < cnt[u], kf[u], cl[u]);
+            // tiles with more than 64 candidates (rare): the rest, 64 at a time
+#pragma unroll
+            for (int u = 0; u < kGatherTiles; ++u) {
+                for (int r0 = 64; r0 < cnt[u]; r0 += 64) {
+                    const int r = r0 + lane;
+                    const int slot = (t0 + u) * ts + (r < cnt[u] ? r : 0);
+                    take(slot, r < cnt[u], s.cand_key[ibase + slot],
+                         s.per_class ? s.cand_cls[ibase + slot] : c);
                 }
             }
         }
