@@ -1238,26 +1238,28 @@ void k_segment_nms(SegArgs s)
                 }
             }
         };
-        for (int t0 = wv * kGatherTiles; t0 < tpi; t0 += kSegWaves * kGatherTiles) {
+        // (tiles are dealt to the waves round-robin, so a few tiles still spread over the waves)
+        for (int t0 = wv; t0 < tpi; t0 += kSegWaves * kGatherTiles) {
             int cnt[kGatherTiles], cl[kGatherTiles];
             float kf[kGatherTiles];
 #pragma unroll
             for (int u = 0; u < kGatherTiles; ++u) {
-                const int tile = t0 + u < tpi ? t0 + u : tpi - 1;
+                const int t = t0 + u * kSegWaves;
+                const int tile = t < tpi ? t : tpi - 1;
                 const int slot = tile * ts + lane;
-                cnt[u] = t0 + u < tpi ? tcount[tile] : 0;
+                cnt[u] = t < tpi ? tcount[tile] : 0;
                 kf[u] = s.cand_key[ibase + slot];
                 cl[u] = s.per_class ? s.cand_cls[ibase + slot] : c;
             }
 #pragma unroll
             for (int u = 0; u < kGatherTiles; ++u)
-                take((t0 + u) * ts + lane, lane < cnt[u], kf[u], cl[u]);
+                take((t0 + u * kSegWaves) * ts + lane, lane < cnt[u], kf[u], cl[u]);
             // tiles with more than 64 candidates (rare): the rest, 64 at a time
 #pragma unroll
             for (int u = 0; u < kGatherTiles; ++u) {
                 for (int r0 = 64; r0 < cnt[u]; r0 += 64) {
                     const int r = r0 + lane;
-                    const int slot = (t0 + u) * ts + (r < cnt[u] ? r : 0);
+                    const int slot = (t0 + u * kSegWaves) * ts + (r < cnt[u] ? r : 0);
                     take(slot, r < cnt[u], s.cand_key[ibase + slot],
                          s.per_class ? s.cand_cls[ibase + slot] : c);
                 }
