@@ -1251,9 +1251,38 @@ void k_segment_nms(SegArgs s)
                 kf[u] = s.cand_key[ibase + slot];
                 cl[u] = s.per_class ? s.cand_cls[ibase + slot] : c;
             }
+            {   // the round's tiles share one reservation of output positions
+                u64 m[kGatherTiles];
+                int total = 0;
 #pragma unroll
-            for (int u = 0; u < kGatherTiles; ++u)
-                take((t0 + u * kSegWaves) * ts + lane, lane < cnt[u], kf[u], cl[u]);
+                for (int u = 0; u < kGatherTiles; ++u) {
+                    const bool valid = lane < cnt[u];
+                    lt += __popcll(__ballot(valid && cl[u] < c));
+                    m[u] = __ballot(valid && cl[u] == c);
+                    total += __popcll(m[u]);
+                }
+                if (total > 0) {
+                    int basepos = 0;
+                    if (lane == 0) basepos = atomicAdd(&s_cnt[1], total);
+                    basepos = __shfl(basepos, 0, 64);
+#pragma unroll
+                    for (int u = 0; u < kGatherTiles; ++u) {
+                        if ((m[u] >> lane) & 1ull) {
+                            const int slot = (t0 + u * kSegWaves) * ts + lane;
+                            const u64 key = ((u64)(~yp_float_order_bits(kf[u])) << 32) |
+                                            (u64)(unsigned int)slot;
+                            const int pos = basepos + __popcll(m[u] & lanes_below(lane));
+                            if (to_lds) {
+                                if (pos < kSortCap) keys_in[pos] = key;
+                                if (pos < kSmallCap) keys_small[pos] = key;
+                            } else {
+                                gdst[pos] = key;
+                            }
+                        }
+                        basepos += __popcll(m[u]);
+                    }
+                }
+            }
             // tiles with more than 64 candidates (rare): the rest, 64 at a time
 #pragma unroll
             for (int u = 0; u < kGatherTiles; ++u) {
