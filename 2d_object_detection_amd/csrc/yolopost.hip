@@ -1138,7 +1138,7 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
 
 template <int MODE>
 #ifndef YP_PAIR_UNROLL
-#define YP_PAIR_UNROLL 4
+#define YP_PAIR_UNROLL 3
 #endif
 #ifndef YP_NMS_MIN_WAVES
 #define YP_NMS_MIN_WAVES 6
