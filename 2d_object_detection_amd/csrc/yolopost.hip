@@ -1707,17 +1707,26 @@ void k_segment_nms(SegArgs s)
 }
 
 // --------------------------------------------------------------------- final row gather
-__global__ void k_gather_rows(GatherArgs g)
+#ifndef YP_GATHER_THREADS
+#define YP_GATHER_THREADS 256
+#endif
+constexpr int kGatherThreads = YP_GATHER_THREADS;
+__global__ __launch_bounds__(kGatherThreads) void k_gather_rows(GatherArgs g)
 {
-    __shared__ int s_part[4];
+    __shared__ int s_part[kGatherThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = blockIdx.x;
     int part = 0;
-    for (int i = tid; i < seg; i += 256) part += g.seg_kept[i];
+    for (int i = tid; i < seg; i += kGatherThreads) part += g.seg_kept[i];
     part = wave_sum(part);
-    if (lane == 0) s_part[wave] = part;
-    __syncthreads();
-    const int prefix = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    int prefix = __shfl(part, 0, 64);   // wave_sum leaves the total in lane 0
+    if (kGatherThreads > 64) {
+        if (lane == 0) s_part[wave] = part;
+        __syncthreads();
+        prefix = 0;
+#pragma unroll
+        for (int w = 0; w < kGatherThreads / 64; ++w) prefix += s_part[w];
+    }
     const int nk = g.seg_kept[seg];
     if (tid == 0) {
         if (seg == g.n_seg - 1) g.out_count[0] = prefix + nk;
@@ -1730,7 +1739,7 @@ __global__ void k_gather_rows(GatherArgs g)
     const int b = seg / g.C, c = seg - b * g.C;
     const size_t ibase = (size_t)b * g.spi;
     const size_t reg = ibase + g.seg_region[seg];
-    for (int k = tid; k < nk; k += 256) {
+    for (int k = tid; k < nk; k += kGatherThreads) {
         const long long d = (long long)prefix + k;
         if (d >= g.cap) break;
         const int slot = g.kept_slot[reg + k];
@@ -2064,7 +2073,7 @@ int finish_v3(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, f
     g.cap = cap;
     g.out_count = out_count;
     g.stats = stats;
-    if (stages & 4) YP_LAUNCH(2, k_gather_rows, dim3(n_seg), dim3(256), 0, st, g);
+    if (stages & 4) YP_LAUNCH(2, k_gather_rows, dim3(n_seg), dim3(kGatherThreads), 0, st, g);
     prof_next();
     return (int)hipGetLastError();
 }
