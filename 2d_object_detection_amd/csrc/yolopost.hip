@@ -561,11 +561,14 @@ void k_front_heads_v3_wave(HeadsArgs ha, CandBuf cb, float conf,
 // ---------------------------------------------------------------- front: reference head
 // Thread t <-> row n = tile*256 + t of image b; a row is the V contiguous floats of one
 // (row, col, anchor) (detect_net.py:153).
-template <bool STAGED>
-__global__ void k_front_grid_ref(const float *pred, int H, int W, int A, int C,
+// CS > 0: the class count is known at compile time (the softmax exponentials are then held in
+// registers and evaluated once); CS == 0 takes it from the argument.
+template <bool STAGED, int CS>
+__global__ void k_front_grid_ref(const float *pred, int H, int W, int A, int C_arg,
                                  AnchorTable at, CandBuf cb, float conf, float im_h,
                                  float im_w)
 {
+    const int C = CS ? CS : C_arg;
     __shared__ u64 s_bal[kRowTile / 64];
     extern __shared__ float s_tile[];
     static_assert(kRowTile == kTileRows, "one record per thread");
@@ -590,11 +593,25 @@ __global__ void k_front_grid_ref(const float *pred, int H, int W, int A, int C,
         float m = t[5];                                         // softmax, :180
         for (int j = 1; j < C; ++j) m = t[5 + j] > m ? t[5 + j] : m;
         float s = 0.f;
-        for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
-        best = obj * (yp_exp(t[5] - m) / s);                    // :107-109
-        for (int j = 1; j < C; ++j) {
-            const float sc = obj * (yp_exp(t[5 + j] - m) / s);
-            if (sc > best) { best = sc; bi = j; }
+        if (CS) {
+            float e[CS ? CS : 1];
+#pragma unroll
+            for (int j = 0; j < CS; ++j) e[j] = yp_exp(t[5 + j] - m);
+#pragma unroll
+            for (int j = 0; j < CS; ++j) s = s + e[j];
+            best = obj * (e[0] / s);                            // :107-109
+#pragma unroll
+            for (int j = 1; j < CS; ++j) {
+                const float sc = obj * (e[j] / s);
+                if (sc > best) { best = sc; bi = j; }
+            }
+        } else {
+            for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
+            best = obj * (yp_exp(t[5] - m) / s);                // :107-109
+            for (int j = 1; j < C; ++j) {
+                const float sc = obj * (yp_exp(t[5 + j] - m) / s);
+                if (sc > best) { best = sc; bi = j; }
+            }
         }
         pass = best >= conf;                                    // :111
         const float hw = w * 0.5f, hh = hgt * 0.5f;             // :95-102, :133
@@ -1788,10 +1805,11 @@ __global__ void k_decode_heads_v3(HeadsArgs ha, float *out_rows)
 
 // Reference predict_transform (detect_net.py:152-183): thread <-> row.  The raw rows come in,
 // and the class probabilities go out, through the tile staging of yp_tile.h.
-template <bool STAGED>
-__global__ void k_decode_grid_ref(const float *pred, int H, int W, int A, int C, AnchorTable at,
+template <bool STAGED, int CS>   // CS as in k_front_grid_ref
+__global__ void k_decode_grid_ref(const float *pred, int H, int W, int A, int C_arg, AnchorTable at,
                                   float *center, float *wh, float *obj, float *cls, long long total)
 {
+    const int C = CS ? CS : C_arg;
     extern __shared__ float s_tile[];
     const long long tile0 = (long long)blockIdx.x * kTileRows;
     const long long o = tile0 + threadIdx.x;
@@ -1814,12 +1832,20 @@ __global__ void k_decode_grid_ref(const float *pred, int H, int W, int A, int C,
         float m = t[5];
         for (int j = 1; j < C; ++j) m = t[5 + j] > m ? t[5 + j] : m;
         float s = 0.f;
-        for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
-        if (STAGED) {
+        if (CS) {   // (always staged)
+#pragma unroll
+            for (int j = 0; j < CS; ++j) probs[j] = yp_exp(t[5 + j] - m);
+#pragma unroll
+            for (int j = 0; j < CS; ++j) s = s + probs[j];
+#pragma unroll
+            for (int j = 0; j < CS; ++j) probs[j] = probs[j] / s;
+        } else if (STAGED) {
+            for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
 #pragma unroll
             for (int j = 0; j < kTileMaxWidth; ++j)
                 if (j < C) probs[j] = yp_exp(t[5 + j] - m) / s;
         } else {
+            for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
             for (int j = 0; j < C; ++j) cls[o * C + j] = yp_exp(t[5 + j] - m) / s;
         }
     }
@@ -2127,12 +2153,16 @@ int yp_predict_transform_reference(const float *d_pred, int batch, int grid_h, i
     if (total >= (1ll << 31)) return YP_ERR_UNSUPPORTED;
     const int blocks = (int)((total + kTileRows - 1) / kTileRows);
     const size_t lds = yp_tile_lds_bytes(5 + num_classes);
-    if (lds)
-        hipLaunchKernelGGL(k_decode_grid_ref<true>, dim3(blocks), dim3(kTileRows), lds,
+    if (lds && num_classes == 5)
+        hipLaunchKernelGGL((k_decode_grid_ref<true, 5>), dim3(blocks), dim3(kTileRows), lds,
+                           (hipStream_t)stream, d_pred, grid_h, grid_w, num_anchors, num_classes, at,
+                           d_center, d_wh, d_obj, d_cls, total);
+    else if (lds)
+        hipLaunchKernelGGL((k_decode_grid_ref<true, 0>), dim3(blocks), dim3(kTileRows), lds,
                            (hipStream_t)stream, d_pred, grid_h, grid_w, num_anchors, num_classes, at,
                            d_center, d_wh, d_obj, d_cls, total);
     else
-        hipLaunchKernelGGL(k_decode_grid_ref<false>, dim3(blocks), dim3(kTileRows), 0,
+        hipLaunchKernelGGL((k_decode_grid_ref<false, 0>), dim3(blocks), dim3(kTileRows), 0,
                            (hipStream_t)stream, d_pred, grid_h, grid_w, num_anchors, num_classes, at,
                            d_center, d_wh, d_obj, d_cls, total);
     return (int)hipGetLastError();
@@ -2297,12 +2327,16 @@ int yp_detect_reference(const YpHead *head, const YpParams *params, float *d_out
     for (int i = 0; i < 2 * head->num_anchors; ++i) at.anc[i] = head->anchors[i];
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = yp_tile_lds_bytes(5 + params->num_classes);
-    if (lds)
-        YP_LAUNCH(0, k_front_grid_ref<true>, dim3(tpi, params->batch), dim3(kRowTile), lds, st,
+    if (lds && params->num_classes == 5)
+        YP_LAUNCH(0, (k_front_grid_ref<true, 5>), dim3(tpi, params->batch), dim3(kRowTile), lds, st,
+                  head->data, head->grid_h, head->grid_w, head->num_anchors, params->num_classes, at,
+                  cb, params->conf_thr, params->im_h, params->im_w);
+    else if (lds)
+        YP_LAUNCH(0, (k_front_grid_ref<true, 0>), dim3(tpi, params->batch), dim3(kRowTile), lds, st,
                   head->data, head->grid_h, head->grid_w, head->num_anchors, params->num_classes, at,
                   cb, params->conf_thr, params->im_h, params->im_w);
     else
-        YP_LAUNCH(0, k_front_grid_ref<false>, dim3(tpi, params->batch), dim3(kRowTile), 0, st,
+        YP_LAUNCH(0, (k_front_grid_ref<false, 0>), dim3(tpi, params->batch), dim3(kRowTile), 0, st,
                   head->data, head->grid_h, head->grid_w, head->num_anchors, params->num_classes, at,
                   cb, params->conf_thr, params->im_h, params->im_w);
     return finish_ref(w, params, (int)spi, tpi, kRowTile, d_out_boxes, d_out_scores, d_out_classes,
