@@ -581,15 +581,28 @@ __global__ void k_front_grid_ref(const float *pred, int H, int W, int A, int C_a
     YpBox bx = {0.f, 0.f, 0.f, 0.f};
     float best = 0.f;
     int bi = 0;
-    if (n < N) {
-        const int a = n % A, k = n / A;
+    float t03[4] = {0.f, 0.f, 0.f, 0.f};   // the box logits, decoded for survivors only when staged
+    constexpr int kRec = 7;                 // floats a survivor parks in the (re-used) tile buffer
+    const bool dense = STAGED && V >= kRec; // (records narrower than that leave no room for it)
+    // box of anchor n of the image from its four logits (detect_net.py:95-102, :133, :155-177)
+    auto decode_box = [&](int n_, const float *tb) {
+        const int a = n_ % A, k = n_ / A;
         const float gx = (float)(k % H), gy = (float)(k / H);   // detect_net.py:155-162
+        const float cx = (yp_sigmoid(tb[0]) + gx) / (float)H;   // :166-168
+        const float cy = (yp_sigmoid(tb[1]) + gy) / (float)W;
+        const float w = (yp_exp(tb[2]) * at.anc[2 * a + 0]) / (float)H;  // :177
+        const float hgt = (yp_exp(tb[3]) * at.anc[2 * a + 1]) / (float)W;
+        const float hw = w * 0.5f, hh = hgt * 0.5f;
+        YpBox r;
+        r.a = (cy - hh) * im_h;
+        r.b = (cx - hw) * im_w;
+        r.c = (cy + hh) * im_h;
+        r.d = (cx + hw) * im_w;
+        return r;
+    };
+    if (n < N) {
         const float *t = STAGED ? s_tile + threadIdx.x * V : tile_src + (size_t)threadIdx.x * V;
-        const float cx = (yp_sigmoid(t[0]) + gx) / (float)H;    // :166-168
-        const float cy = (yp_sigmoid(t[1]) + gy) / (float)W;
         const float obj = yp_sigmoid(t[4]);                     // :171
-        const float w = (yp_exp(t[2]) * at.anc[2 * a + 0]) / (float)H;  // :177
-        const float hgt = (yp_exp(t[3]) * at.anc[2 * a + 1]) / (float)W;
         float m = t[5];                                         // softmax, :180
         for (int j = 1; j < C; ++j) m = t[5 + j] > m ? t[5 + j] : m;
         float s = 0.f;
@@ -614,15 +627,37 @@ __global__ void k_front_grid_ref(const float *pred, int H, int W, int A, int C_a
             }
         }
         pass = best >= conf;                                    // :111
-        const float hw = w * 0.5f, hh = hgt * 0.5f;             // :95-102, :133
-        bx.a = (cy - hh) * im_h;
-        bx.b = (cx - hw) * im_w;
-        bx.c = (cy + hh) * im_h;
-        bx.d = (cx + hw) * im_w;
+        if (dense) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t03[q] = t[q];
+        } else {
+            bx = decode_box(n, t);
+        }
     }
     int total;
-    const int rank = tile_rank_rows(pass, s_bal, total);
-    if (pass) store_cand(cb, ((size_t)b * cb.tpi + tile) * cb.ts + rank, bx, best, 0.f, bi);
+    const int rank = tile_rank_rows(pass, s_bal, total);   // (barrier inside: the tile has been read)
+    const size_t slot0 = ((size_t)b * cb.tpi + tile) * cb.ts;
+    if (dense) {
+        // survivors park what their box needs; thread r then decodes the tile's r-th survivor, so
+        // the four transcendentals of a box are evaluated for survivors only
+        if (pass) {
+            float *rec = s_tile + rank * kRec;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rec[q] = t03[q];
+            rec[4] = __int_as_float(n);
+            rec[5] = best;
+            rec[6] = __int_as_float(bi);
+        }
+        __syncthreads();
+        const int r = threadIdx.x;
+        if (r < total) {
+            const float *rec = s_tile + r * kRec;
+            const YpBox rb = decode_box(__float_as_int(rec[4]), rec);
+            store_cand(cb, slot0 + r, rb, rec[5], 0.f, __float_as_int(rec[6]));
+        }
+    } else if (pass) {
+        store_cand(cb, slot0 + rank, bx, best, 0.f, bi);
+    }
     if (threadIdx.x == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = total;
 }
 
