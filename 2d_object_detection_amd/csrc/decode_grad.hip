@@ -27,9 +27,11 @@ struct GradAnchors {
 
 constexpr int kGradMaxClasses = 64;
 
-template <bool STAGED>
+// CS > 0: the class count is known at compile time and the softmax probabilities are held in
+// registers (evaluated once); CS == 0 takes the count from the argument and re-evaluates them.
+template <bool STAGED, int CS>
 __global__ void __launch_bounds__(kTileRows)
-k_decode_grid_ref_backward(const float *__restrict__ pred, int H, int W, int A, int C, GradAnchors at,
+k_decode_grid_ref_backward(const float *__restrict__ pred, int H, int W, int A, int C_arg, GradAnchors at,
                            const float *__restrict__ g_center, const float *__restrict__ g_wh,
                            const float *__restrict__ g_obj, const float *__restrict__ g_cls,
                            float *__restrict__ g_pred, long long total)
@@ -39,6 +41,7 @@ k_decode_grid_ref_backward(const float *__restrict__ pred, int H, int W, int A, 
     extern __shared__ float s_tile[];
     const long long tile0 = (long long)blockIdx.x * kTileRows;
     const long long o = tile0 + threadIdx.x;
+    const int C = CS ? CS : C_arg;
     const int V = 5 + C;
     float *s_gcls = s_tile + kTileRows * V;
     if (STAGED) {
@@ -66,20 +69,33 @@ k_decode_grid_ref_backward(const float *__restrict__ pred, int H, int W, int A, 
         float m = t[5];
         for (int j = 1; j < C; ++j) m = t[5 + j] > m ? t[5 + j] : m;
         float s = 0.0f;
-        for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
+        float pj[CS ? CS : 1];
+        if (CS) {
+#pragma unroll
+            for (int j = 0; j < CS; ++j) pj[j] = yp_exp(t[5 + j] - m);
+#pragma unroll
+            for (int j = 0; j < CS; ++j) s = s + pj[j];
+#pragma unroll
+            for (int j = 0; j < CS; ++j) pj[j] = pj[j] / s;
+        } else {
+            for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
+        }
+        auto prob = [&](int j) { return CS ? pj[CS ? j : 0] : yp_exp(t[5 + j] - m) / s; };
         const float *gp = STAGED ? s_gcls + threadIdx.x * C : g_cls + o * C;
         float dot = 0.0f;
-        if (g_cls)
-            for (int j = 0; j < C; ++j) dot = dot + gp[j] * (yp_exp(t[5 + j] - m) / s);
+        if (g_cls) {
+#pragma unroll
+            for (int j = 0; j < (CS ? CS : C); ++j) dot = dot + gp[j] * prob(j);
+        }
         if (STAGED) {
 #pragma unroll
             for (int j = 0; j < kTileMaxWidth - 5; ++j)
-                if (j < C) gt[5 + j] = g_cls ? (gp[j] - dot) * (yp_exp(t[5 + j] - m) / s) : 0.0f;
+                if (j < C) gt[5 + j] = g_cls ? (gp[j] - dot) * prob(j) : 0.0f;
         } else {
             float *out = g_pred + o * V;
             for (int v = 0; v < 5; ++v) out[v] = gt[v];
             for (int j = 0; j < C; ++j)
-                out[5 + j] = g_cls ? (gp[j] - dot) * (yp_exp(t[5 + j] - m) / s) : 0.0f;
+                out[5 + j] = g_cls ? (gp[j] - dot) * prob(j) : 0.0f;
         }
     }
     if (STAGED) {
@@ -111,10 +127,10 @@ struct LossWeights {
 
 constexpr int kLossThreads = 256;
 
-template <bool STAGED>
+template <bool STAGED, int CS>   // CS as in k_decode_grid_ref_backward
 __global__ void __launch_bounds__(kLossThreads)
 k_loss_custom_ref(const float *__restrict__ pred, const float *__restrict__ truth, int H, int W, int A,
-                  int C, GradAnchors at, LossWeights lw, float *__restrict__ g_pred,
+                  int C_arg, GradAnchors at, LossWeights lw, float *__restrict__ g_pred,
                   float *__restrict__ partials, long long total)
 {
     // STAGED: [0, 256 V) the raw rows, later the gradient rows; then 256 x 5 target values
@@ -123,6 +139,7 @@ k_loss_custom_ref(const float *__restrict__ pred, const float *__restrict__ trut
     static_assert(kLossThreads == kTileRows, "one record per thread");
     const long long tile0 = (long long)blockIdx.x * kTileRows;
     const long long o = tile0 + threadIdx.x;
+    const int C = CS ? CS : C_arg;
     const int V = 5 + C;
     float *s_truth = s_tile + kTileRows * V;
     if (STAGED) {
@@ -167,11 +184,23 @@ k_loss_custom_ref(const float *__restrict__ pred, const float *__restrict__ trut
         float mx = t[5];
         for (int j = 1; j < C; ++j) mx = t[5 + j] > mx ? t[5 + j] : mx;
         float se = 0.0f;
-        for (int j = 0; j < C; ++j) se = se + yp_exp(t[5 + j] - mx);
+        float pj[CS ? CS : 1];
+        if (CS) {
+#pragma unroll
+            for (int j = 0; j < CS; ++j) pj[j] = yp_exp(t[5 + j] - mx);
+#pragma unroll
+            for (int j = 0; j < CS; ++j) se = se + pj[j];
+#pragma unroll
+            for (int j = 0; j < CS; ++j) pj[j] = pj[j] / se;
+        } else {
+            for (int j = 0; j < C; ++j) se = se + yp_exp(t[5 + j] - mx);
+        }
+        auto prob = [&](int j) { return CS ? pj[CS ? j : 0] : yp_exp(t[5 + j] - mx) / se; };
         const int cls_id = (int)y[4];  // tf.cast(..., tf.int32), train.py:177
         float dot = 0.0f;              // sum_j (dL/dp_j) * p_j for the softmax backward
-        for (int j = 0; j < C; ++j) {
-            const float p = yp_exp(t[5 + j] - mx) / se;
+#pragma unroll
+        for (int j = 0; j < (CS ? CS : C); ++j) {
+            const float p = prob(j);
             const float e = ((j == cls_id) ? 1.0f : 0.0f) - p;
             l_cls = l_cls + m * (e * e);  // :179
             dot = dot + (-(m * e)) * p;
@@ -190,7 +219,7 @@ k_loss_custom_ref(const float *__restrict__ pred, const float *__restrict__ trut
 #pragma unroll
                 for (int j = 0; j < kTileMaxWidth - 5; ++j) {
                     if (j < C) {
-                        const float p = yp_exp(t[5 + j] - mx) / se;
+                        const float p = prob(j);
                         const float e = ((j == cls_id) ? 1.0f : 0.0f) - p;
                         gt[5 + j] = (-(m * e) - dot) * p;
                     }
@@ -199,7 +228,7 @@ k_loss_custom_ref(const float *__restrict__ pred, const float *__restrict__ trut
                 float *out = g_pred + o * V;
                 for (int v = 0; v < 5; ++v) out[v] = gt[v];
                 for (int j = 0; j < C; ++j) {
-                    const float p = yp_exp(t[5 + j] - mx) / se;
+                    const float p = prob(j);
                     const float e = ((j == cls_id) ? 1.0f : 0.0f) - p;
                     out[5 + j] = (-(m * e) - dot) * p;
                 }
@@ -293,13 +322,18 @@ extern "C" int yp_loss_custom_reference(const float *d_pred, const float *d_true
     const LossWeights lw = {coord_weight, obj_weight, noobj_weight, iou_thr};
     float *partials = (float *)d_workspace;
     const int V = 5 + num_classes;
-    if (V <= kTileMaxWidth)
-        hipLaunchKernelGGL(k_loss_custom_ref<true>, dim3((unsigned)blocks), dim3(kLossThreads),
+    if (num_classes == 5)
+        hipLaunchKernelGGL((k_loss_custom_ref<true, 5>), dim3((unsigned)blocks), dim3(kLossThreads),
+                           (size_t)kTileRows * (V + 5) * sizeof(float), (hipStream_t)stream, d_pred,
+                           d_true_grid, grid_h, grid_w, num_anchors, num_classes, at, lw, d_grad_pred,
+                           partials, total);
+    else if (V <= kTileMaxWidth)
+        hipLaunchKernelGGL((k_loss_custom_ref<true, 0>), dim3((unsigned)blocks), dim3(kLossThreads),
                            (size_t)kTileRows * (V + 5) * sizeof(float), (hipStream_t)stream, d_pred,
                            d_true_grid, grid_h, grid_w, num_anchors, num_classes, at, lw, d_grad_pred,
                            partials, total);
     else
-        hipLaunchKernelGGL(k_loss_custom_ref<false>, dim3((unsigned)blocks), dim3(kLossThreads), 0,
+        hipLaunchKernelGGL((k_loss_custom_ref<false, 0>), dim3((unsigned)blocks), dim3(kLossThreads), 0,
                            (hipStream_t)stream, d_pred, d_true_grid, grid_h, grid_w, num_anchors,
                            num_classes, at, lw, d_grad_pred, partials, total);
     hipError_t e = hipGetLastError();
@@ -324,13 +358,18 @@ extern "C" int yp_predict_transform_reference_backward(
     const long long blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return YP_ERR_UNSUPPORTED;
     const int V = 5 + num_classes;
-    if (V <= kTileMaxWidth)
-        hipLaunchKernelGGL(k_decode_grid_ref_backward<true>, dim3((unsigned)blocks), dim3(kTileRows),
+    if (num_classes == 5)
+        hipLaunchKernelGGL((k_decode_grid_ref_backward<true, 5>), dim3((unsigned)blocks), dim3(kTileRows),
+                           (size_t)kTileRows * (V + num_classes) * sizeof(float), (hipStream_t)stream,
+                           d_pred, grid_h, grid_w, num_anchors, num_classes, at, d_grad_center,
+                           d_grad_wh, d_grad_obj, d_grad_cls, d_grad_pred, total);
+    else if (V <= kTileMaxWidth)
+        hipLaunchKernelGGL((k_decode_grid_ref_backward<true, 0>), dim3((unsigned)blocks), dim3(kTileRows),
                            (size_t)kTileRows * (V + num_classes) * sizeof(float), (hipStream_t)stream,
                            d_pred, grid_h, grid_w, num_anchors, num_classes, at, d_grad_center,
                            d_grad_wh, d_grad_obj, d_grad_cls, d_grad_pred, total);
     else
-        hipLaunchKernelGGL(k_decode_grid_ref_backward<false>, dim3((unsigned)blocks), dim3(kTileRows), 0,
+        hipLaunchKernelGGL((k_decode_grid_ref_backward<false, 0>), dim3((unsigned)blocks), dim3(kTileRows), 0,
                            (hipStream_t)stream, d_pred, grid_h, grid_w, num_anchors, num_classes, at,
                            d_grad_center, d_grad_wh, d_grad_obj, d_grad_cls, d_grad_pred, total);
     return (int)hipGetLastError();
