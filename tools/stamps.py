@@ -22,7 +22,7 @@ inp = os.environ.get("INP", "416")
 inp = tuple(int(v) for v in inp.split(",")) if "," in inp else int(inp)
 CONF = float(os.environ.get("CONF", 0.5))
 dev = torch.device("cuda:0")
-heads = [h.to(dev) for h in syn.make_heads(B, inp, 5, seed=1)]
+heads = [h.to(dev) for h in syn.make_heads(B, inp, 5, seed=1, clustered=bool(int(os.environ.get("CLUSTERED", "0"))))]
 eng = util.YoloV3Post(B, inp, 5, CONF, 0.4, device=dev)
 nseg = B * 5
 dbg = torch.zeros((nseg, 32), dtype=torch.int64, device=dev)
