@@ -418,6 +418,17 @@ def main():
                            "nms_iou_pairs_per_s": round(float(pairs.astype(np.int64).sum())
                                                         / (nms_ms * 1e-3), 1)},
         }
+        # NMS against the vector units' peak: one IoU test is ~22 VALU instructions per pair
+        # (4 min/max, 2 sub+add, 2 clamps, product, union, 2 band products, 3-4 compares and
+        # selects), the chip issues 256 CUs x 64 lanes per cycle at 2.4 GHz
+        ops_per_pair, lane_ops_peak = 22.0, 256 * 64 * 2.4e9
+        pairs_per_s = float(pairs.astype(np.int64).sum()) / (nms_ms * 1e-3)
+        out["nms_roofline"] = {"bound": "valu", "achieved": round(pairs_per_s / 1e9, 2),
+                               "peak": round(lane_ops_peak / ops_per_pair / 1e9, 1), "unit": "G IoU pairs/s",
+                               "frac": round(pairs_per_s * ops_per_pair / lane_ops_peak, 4),
+                               "ops_per_pair": ops_per_pair,
+                               "note": "pairs the kernel evaluated / its HIP-event time; the kernel also "
+                                       "gathers, sorts and sweeps, so this is a lower bound on the tile rate"}
         if world > 1:
             out["config"]["exchange"] = (
                 "final: detections stay sharded by image during the steps; one variable-length RCCL "
