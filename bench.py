@@ -87,7 +87,8 @@ def front_kernel_roofline(config_name, dev, launches=30):
     achieved = alg / (front_ms * 1e-3) / 1e9
     return {"workload": "%s: %s" % (config_name, desc), "bound": "hbm", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "algorithmic_bytes": int(alg), "kernel_ms": round(front_ms, 5), "launches": calls}
+            "algorithmic_bytes": int(alg), "kernel_ms": round(front_ms, 5), "launches": calls,
+            "regime": "one batch at a time on one stream (as frac_alone)"}
 
 
 def cpu_baseline(cpu_heads, inp_dim, conf, nms, budget_s=10.0):
