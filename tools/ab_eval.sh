@@ -10,8 +10,8 @@ for rep in 1 2 3; do
 import json, sys
 d = json.loads(open("gpurun_out/ab_one.json").read().strip().splitlines()[-1])
 k = d["kernels_ms"]
-print("%-24s %10.1f images/s  in flight %d  front %.5f nms %.5f gather %.5f" % (
-    sys.argv[1], d["value"], d["config"]["batches_in_flight"], k["front"], k["segment_nms"], k["gather"]))
+print("%-24s %10.1f images/s  in flight %d  front %.5f nms %.5f gather %.5f  alone %s" % (
+    sys.argv[1], d["value"], d["config"]["batches_in_flight"], k["front"], k["segment_nms"], k["gather"], k.get("alone")))
 PY
     done
   done
