@@ -1,6 +1,7 @@
 """Experiment: replay the three-kernel path from a HIP graph (several batches per graph, each on
 its own captured stream) and compare with eager launches."""
 import importlib, os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 yp = importlib.import_module("2d_object_detection_amd")
@@ -8,7 +9,7 @@ syn, util = yp.synthetic, yp.util
 dev = torch.device("cuda:0")
 B, inp = 64, 416
 heads = [h.to(dev) for h in syn.make_heads(B, inp, 5, seed=1)]
-for n_eng, reps in ((1, 1), (3, 1), (3, 2), (3, 4), (4, 1), (6, 1)):
+for n_eng, reps in ((1, 1), (3, 1), (4, 1), (4, 2), (4, 4)):
     engines = [util.YoloV3Post(B, inp, 5, 0.5, 0.4, device=dev) for _ in range(n_eng)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_eng)]
     for e, s in zip(engines, streams):
