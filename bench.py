@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--clustered", action="store_true",
                     help="overlapping boxes around object centres instead of i.i.d. boxes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0,
+                    help="CPU work spent on the cpu_baseline leg (N = 1 only)")
     ap.add_argument("--exchange", default="final", choices=["final", "every-step"],
                     help="N > 1: when the ranks exchange detection rows (see timed_run)")
     ap.add_argument("--workload", default="detect",
@@ -463,7 +465,7 @@ def main():
             del engines
             out["roofline_large_input"] = front_kernel_roofline("cfg3", dev)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cpu_heads, inp_dim, conf, nms)
+            out["cpu_baseline"] = cpu_baseline(cpu_heads, inp_dim, conf, nms, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
