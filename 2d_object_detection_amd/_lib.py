@@ -156,8 +156,34 @@ def as_f32(t, name):
     return t.contiguous()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device):
+    """The current HIP stream of ``device`` as a void pointer (raw handle when torch exposes it
+    directly: several microseconds cheaper per call than building a torch.cuda.Stream)."""
+    if _raw_stream is not None and device.index is not None:
+        return ctypes.c_void_p(_raw_stream(device.index))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def on_device(device):
+    """Context in which ``device`` is the current device (kernels are launched on the current
+    device); free when it already is."""
+    if device.index is None or torch.cuda.current_device() == device.index:
+        return _NO_SWITCH
+    return torch.cuda.device(device)
 
 
 def workspace(nbytes, device):

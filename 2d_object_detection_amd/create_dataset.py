@@ -65,7 +65,7 @@ def encode_true_box_grids(objects, device=None):
     if B == 0:
         return grid, mask
     anc = _anchors()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.load().yp_encode_true_box_grid(
             rows.data_ptr(), offsets.data_ptr(), B, H, W, A,
             anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
@@ -105,7 +105,7 @@ def decode_true_box_grids_device(true_box_grid):
     L = _lib.load()
     ws = _lib.workspace(L.yp_true_box_grid_workspace_bytes(B, H, W, A), dev)
     anc = _anchors()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = L.yp_decode_true_box_grid(
             g.data_ptr(), B, H, W, A, anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
             int(params.im_height), int(params.im_width), index.data_ptr(), boxes.data_ptr(),

@@ -109,7 +109,7 @@ def _decode_forward(pred, H, W, A, C):
     if B == 0:
         return center, wh, obj, cls
     anc = _anchor_array(A)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.load().yp_predict_transform_reference(
             pred.data_ptr(), B, H, W, A, C,
             anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
@@ -141,7 +141,7 @@ class _PredictTransform(torch.autograd.Function):
         gs = [None if g is None else _lib.as_f32(g, "upstream gradient")
               for g in (g_center, g_wh, g_obj, g_cls)]
         anc = _anchor_array(A)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.load().yp_predict_transform_reference_backward(
                 pred.data_ptr(), B, H, W, A, C,
                 anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
@@ -210,7 +210,7 @@ class DetectNet():
         L = _lib.load()
         outs = _alloc_outputs(B, dev)
         ws = _lib.workspace(L.yp_rows_workspace_bytes(B, N, 1), dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.yp_filter_boxes_reference(
                 center.data_ptr(), wh.data_ptr(), obj.data_ptr(), cls.data_ptr(), N,
                 ctypes.byref(p), *[o.data_ptr() for o in outs], ws.data_ptr(), ws.numel(),
@@ -236,7 +236,7 @@ class DetectNet():
         L = _lib.load()
         outs = _alloc_outputs(B, dev)
         ws = _lib.workspace(L.yp_detect_reference_workspace_bytes(B, H, W, A), dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.yp_detect_reference(ctypes.byref(head), ctypes.byref(p),
                                        *[o.data_ptr() for o in outs], ws.data_ptr(), ws.numel(),
                                        _lib.stream_ptr(dev))

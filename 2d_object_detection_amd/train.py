@@ -35,7 +35,7 @@ class _LossCustom(torch.autograd.Function):
         grad = torch.empty_like(pred) if need_grad else None
         ws = _lib.workspace(L.yp_loss_custom_reference_workspace_bytes(B, H, W, A), dev)
         anc = _anchor_array(A)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.yp_loss_custom_reference(
                 pred.data_ptr(), true_grid.data_ptr(), B, H, W, A, C,
                 anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), *[float(w) for w in weights],

@@ -65,7 +65,7 @@ def predict_transform_heads(heads, inp_dim, anchors_per_head, num_classes):
     rows = torch.empty((B, N, 5 + num_classes), dtype=torch.float32, device=dev)
     if B == 0:
         return rows
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.load().yp_predict_transform_yolov3(descs, len(heads), B, num_classes,
                                                      rows.data_ptr(), _lib.stream_ptr(dev))
     _lib.check(rc, "yp_predict_transform_yolov3")
@@ -102,7 +102,7 @@ def write_results_device(prediction, confidence, num_classes, nms_conf=0.4, out_
     L = _lib.load()
     p = _v3_params(B, num_classes, confidence, nms_conf)
     ws = _lib.workspace(L.yp_rows_workspace_bytes(B, N, num_classes), dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = L.yp_write_results(pred.data_ptr(), N, ctypes.byref(p), out.data_ptr(), cap,
                                 count.data_ptr(), stats.data_ptr() if want_stats else None,
                                 ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
@@ -134,7 +134,7 @@ def bbox_iou(box1, box2):
     out = torch.empty((M,), dtype=torch.float32, device=b2.device)
     if M == 0:
         return out
-    with torch.cuda.device(b2.device):
+    with _lib.on_device(b2.device):
         rc = _lib.load().yp_bbox_iou(b1.data_ptr(), b2.data_ptr(), M, b2.shape[1], out.data_ptr(),
                                      _lib.stream_ptr(b2.device))
     _lib.check(rc, "yp_bbox_iou")
@@ -156,6 +156,8 @@ class YoloV3Post:
                                    else "cuda:%d" % torch.cuda.current_device())
         if self.device.type != "cuda":
             raise _lib.YoloPostError("YoloV3Post needs a ROCm device; there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.batch, self.inp_dim, self.num_classes = int(batch), inp_dim, int(num_classes)
         self.anchors, self.strides = anchors, tuple(strides)
         in_h, in_w = _dims(inp_dim)
@@ -221,9 +223,10 @@ class YoloV3Post:
             if len(self._desc_cache) > 64:
                 self._desc_cache.clear()
             self._desc_cache[key] = descs
-        stream = (torch.cuda.current_stream(self.device) if stream is None else stream).cuda_stream
-        rc = self._detect(descs, len(descs), self._params_ref, self._out_ptr, self.cap,
-                          self._count_ptr, self._stats_ptr, self._ws_ptr, self._ws_bytes, stream)
+        stream = _lib.stream_ptr(self.device) if stream is None else stream.cuda_stream
+        with _lib.on_device(self.device):   # kernels go to the current device: make it the engine's
+            rc = self._detect(descs, len(descs), self._params_ref, self._out_ptr, self.cap,
+                              self._count_ptr, self._stats_ptr, self._ws_ptr, self._ws_bytes, stream)
         if rc != 0:
             _lib.check(rc, "yp_detect_yolov3")
         return self.out, self.count
