@@ -186,6 +186,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a single GPU: take the multi-rank code path (process group, barriers, final
+    # exchange) with a world of one rank
+    multi = world > 1 or os.environ.get("YP_BENCH_FORCE_DIST") == "1"
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run"
                          % (args.gpus, world))
@@ -195,9 +198,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")   # (torch.distributed.run sets both)
         backend = os.environ.get("YP_BENCH_BACKEND", "nccl")   # nccl = RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -231,7 +235,7 @@ def main():
         n_eng = max(rates, key=rates.get)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -243,7 +247,7 @@ def main():
         "every-step" one fixed-capacity all-gather of every rank's rows after every step, enqueued
                      behind the kernels and overlapped with the following steps"""
         gathers, engines = [], []
-        per_step = world > 1 and exchange == "every-step"
+        per_step = multi and exchange == "every-step"
 
         def build(gather_cap):
             gathers.clear()
@@ -295,10 +299,17 @@ def main():
         for i in range(warmup):
             step(i)
         drain()
-        if world > 1 and not per_step:
-            # the exchange is warmed up like the kernels: RCCL connects its channels on a
-            # collective's first use
-            dsb.all_gather_rows(torch.zeros((64, 8), device=dev), 64)
+        if multi and not per_step:
+            # the exchange is warmed up like the kernels, with a real batch's detection list: the
+            # first RCCL collective of a given size class costs 30-130 ms (measured,
+            # tools/exp_exchange_cost.py), later ones 0.2-0.3 ms
+            if last[0] is None:
+                last[0] = engines[0].run(heads, streams[0])
+            for _ in range(2):
+                with torch.cuda.stream(streams[0]):
+                    streams[0].wait_stream(torch.cuda.current_stream(dev))
+                    torch.cuda.synchronize()
+                    dsb.all_gather_rows(last[0][0], last[0][1])
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -306,14 +317,14 @@ def main():
         t_enqueued = time.perf_counter() - t0
         drain()
         info = {}
-        if world > 1 and not per_step:
+        if multi and not per_step:
             rows, count = last[0]
             with torch.cuda.stream(streams[(steps - 1) % n_eng]):   # behind the last batch's kernels
                 gathered, counts = dsb.all_gather_rows(rows, count)
             info = {"gather_rows_last_step": counts, "gathered_rows": int(gathered.shape[0])}
         fence()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -327,7 +338,7 @@ def main():
 
     elapsed, t_enqueued, engines, xinfo = timed_run(args.exchange, args.steps, args.warmup)
     other = None
-    if world > 1 and args.also_other_exchange:
+    if multi and args.also_other_exchange:
         # the other exchange mode on a shorter loop, reported next to the headline
         other_mode = "every-step" if args.exchange == "final" else "final"
         o_steps = max(10, min(args.steps, 60))
@@ -449,7 +460,7 @@ def main():
                                "ops_per_pair": ops_per_pair,
                                "note": "pairs the kernel evaluated / its HIP-event time; the kernel also "
                                        "gathers, sorts and sweeps, so this is a lower bound on the tile rate"}
-        if world > 1:
+        if multi:
             out["config"]["exchange"] = (
                 "final: detections stay sharded by image during the steps; one variable-length RCCL "
                 "all-gather of the last batch's detection rows closes the timed region"
@@ -467,7 +478,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cpu_heads, inp_dim, conf, nms, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
