@@ -35,7 +35,10 @@ typedef unsigned long long u64;
 constexpr int kRowTile = 256;     // rows per tile in the row-mapped front kernels
 constexpr int kFrontGroups = 2;   // 64-cell groups per tile of the YOLOv3 heads front kernel
 constexpr int kFrontCells = 64 * kFrontGroups;
-constexpr int kStageWin = 128;    // survivors staged per round by the single-wave front kernel
+#ifndef YP_STAGE_WIN
+#define YP_STAGE_WIN 128
+#endif
+constexpr int kStageWin = YP_STAGE_WIN;    // survivors staged per round by the single-wave front kernel
 constexpr int kSegThreads = 512;  // threads per NMS workgroup (the kernel is only validated for 512)
 constexpr int kSegWaves = kSegThreads / 64;
 constexpr int kSortCap = 2048;    // largest segment whose keys are gathered straight into LDS
