@@ -15,6 +15,8 @@ LIB_PATH = os.environ.get("YOLOPOST_LIB") or os.path.join(_HERE, "libyolopost.so
 
 YP_MAX_HEADS = 4
 YP_MAX_ANCHORS = 8
+YP_MAX_SETS = 8
+YP_STATS_PLANES = 4   # survivors, kept, IoU pairs evaluated, IoU-at-threshold ties
 YP_MODE_YOLOV3 = 0
 YP_MODE_REFERENCE = 1
 
@@ -22,7 +24,7 @@ YP_MODE_REFERENCE = 1
 EXPORTED_SYMBOLS = (
     "yp_version", "yp_strerror",
     "yp_predict_transform_reference", "yp_predict_transform_yolov3",
-    "yp_detect_yolov3_workspace_bytes", "yp_detect_yolov3",
+    "yp_detect_yolov3_workspace_bytes", "yp_detect_yolov3", "yp_detect_yolov3_multi",
     "yp_detect_reference_workspace_bytes", "yp_detect_reference",
     "yp_rows_workspace_bytes", "yp_write_results", "yp_filter_boxes_reference",
     "yp_bbox_iou", "yp_profile_start", "yp_profile_stop",
@@ -93,6 +95,9 @@ def load():
     L.yp_detect_yolov3.restype = i32
     L.yp_detect_yolov3.argtypes = [ctypes.POINTER(YpHead), i32, ctypes.POINTER(YpParams), vp, i64,
                                    vp, vp, vp, sz, vp]
+    L.yp_detect_yolov3_multi.restype = i32
+    L.yp_detect_yolov3_multi.argtypes = [ctypes.POINTER(YpHead), i32, i32, ctypes.POINTER(YpParams),
+                                         vp, i64, vp, vp, vp, sz, vp]
     L.yp_detect_reference_workspace_bytes.restype = sz
     L.yp_detect_reference_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.yp_detect_reference.restype = i32

@@ -62,11 +62,16 @@ struct HeadGeom {
 };
 
 struct HeadsArgs {
-    HeadGeom h[YP_MAX_HEADS];
+    HeadGeom h[YP_MAX_HEADS];   // geometry shared by every set; h[i].data = head i of set 0
+    // Head tensors of every set (independent batches of identical geometry handled by one
+    // launch): set s, head i.  blockIdx.z selects the set; image b of set s is image
+    // s * bps + b of the launch, which is how the workspace and the segments number it.
+    const float *data[YP_MAX_SETS][YP_MAX_HEADS];
     int n_heads;
     int tpi;   // tiles per image
     int C;     // classes
     int N;     // rows per image over all heads
+    int bps;   // images per set
     unsigned long long *dbg;  // diagnostic builds only (YP_STAMPS)
 };
 
@@ -105,6 +110,8 @@ struct SegArgs {
     int *seg_cand;           // [n_seg]
     int *seg_region;         // [n_seg] region start inside the image
     unsigned int *seg_pairs; // [n_seg] IoU evaluations (low 32 bits)
+    unsigned int *seg_ties;  // [n_seg] evaluated pairs whose IoU lay within 2^-20 (relative) of the
+                             // threshold, i.e. that needed the exact divide-and-compare
     // reference-mode outputs, padded to max_out rows per image
     float *out_boxes;
     float *out_scores;
@@ -131,6 +138,8 @@ struct SegArgs {
 
 struct GatherArgs {
     int n_seg, C, spi, batch_offset;
+    int spset;               // segments per set (images per set x classes)
+    long long set_stride;    // floats between the output rows of consecutive sets
     const float4 *cand_box;
     const float *cand_key;
     const float *cand_aux;
@@ -139,6 +148,7 @@ struct GatherArgs {
     const int *seg_cand;
     const int *seg_region;
     const unsigned int *seg_pairs;
+    const unsigned int *seg_ties;
     float *out_rows;
     long long cap;
     int *out_count;
@@ -259,12 +269,14 @@ __global__ void k_front_heads_v3(HeadsArgs ha, CandBuf cb, float conf, float t_l
     __shared__ u64 s_bal[kFrontGroups * YP_MAX_ANCHORS];
     extern __shared__ float s_stage[];
     constexpr int kStride = 6 + CS;  // t0..t4, packed (anchor, cell), CS class logits
-    const int tile = blockIdx.x, b = blockIdx.y;
+    const int tile = blockIdx.x, bl = blockIdx.y, set = blockIdx.z;
+    const int b = set * ha.bps + bl;     // image index inside the launch
     int h = 0;
 #pragma unroll
     for (int i = 1; i < YP_MAX_HEADS; ++i)
         if (i < ha.n_heads && tile >= ha.h[i].tile_begin) h = i;
     const HeadGeom &g = ha.h[h];
+    const float *gdata = ha.data[set][h];
     const int n_anchor = blockDim.x / kFrontCells;
     // wave-uniform quantities are made scalar so that the plane base addresses are computed
     // once on the scalar unit and every load is "scalar base + lane offset"
@@ -280,7 +292,7 @@ __global__ void k_front_heads_v3(HeadsArgs ha, CandBuf cb, float conf, float t_l
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f;
     float tc[CS ? CS : 1];
     if (active) {
-        const float *plane = g.data + ((size_t)(b * g.A + a) * V) * cells;   // scalar
+        const float *plane = gdata + ((size_t)(bl * g.A + a) * V) * cells;   // scalar
         t4 = (plane + (size_t)4 * cells)[cell];
         t0 = plane[cell];
         t1 = (plane + (size_t)1 * cells)[cell];
@@ -328,7 +340,7 @@ __global__ void k_front_heads_v3(HeadsArgs ha, CandBuf cb, float conf, float t_l
                 if (sc > best) { best = sc; bi = j; }
             }
         } else {
-            const float *p = g.data + ((size_t)(b * g.A + sa) * V) * cells + scell;
+            const float *p = gdata + ((size_t)(bl * g.A + sa) * V) * cells + scell;
             best = yp_sigmoid(p[(size_t)5 * cells]);
             for (int j = 1; j < C; ++j) {
                 const float sc = yp_sigmoid(p[(size_t)(5 + j) * cells]);
@@ -360,15 +372,17 @@ void k_front_heads_v3_wave(HeadsArgs ha, CandBuf cb, float conf,
                                                  // padded so that a record is whole float4s
     constexpr int V = 5 + CS;
     static_assert(kFrontCells == 128, "two cells per lane");
-    const int tile = blockIdx.x, b = blockIdx.y;
+    const int tile = blockIdx.x, bl = blockIdx.y, set = blockIdx.z;
+    const int b = set * ha.bps + bl;     // image index inside the launch
     int h = 0;
 #pragma unroll
     for (int i = 1; i < YP_MAX_HEADS; ++i)
         if (i < ha.n_heads && tile >= ha.h[i].tile_begin) h = i;
     const HeadGeom &g = ha.h[h];
+    const float *gdata = ha.data[set][h];
     const int lane = threadIdx.x;
 #ifdef YP_STAMPS
-    const size_t dbg_blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t dbg_blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (lane == 0 && ha.dbg) ha.dbg[dbg_blk * 4 + 0] = wall_clock64();
 #endif
     const int cells = g.gh * g.gw;
@@ -382,8 +396,8 @@ void k_front_heads_v3_wave(HeadsArgs ha, CandBuf cb, float conf,
     // the 8-byte form can be used is decided once for the whole tile (cell0 is even, so with
     // an even plane size every plane slice starts on the parity of the head's base address);
     // otherwise lanes past the last cell read cell 0 of the slice instead of branching.
-    const float *img = g.data + (size_t)b * NA * V * cells + cell0;   // scalar
-    const bool wide = ((reinterpret_cast<uintptr_t>(g.data) & 7) == 0) && ((cells & 1) == 0) &&
+    const float *img = gdata + (size_t)bl * NA * V * cells + cell0;   // scalar
+    const bool wide = ((reinterpret_cast<uintptr_t>(gdata) & 7) == 0) && ((cells & 1) == 0) &&
                       (cell0 + kFrontCells <= cells);
     if (wide) {
         // (loaded as one 64-bit integer: as two floats the optimiser folds this branch and the
@@ -895,7 +909,8 @@ constexpr int kColUnroll = YP_COL_UNROLL;
 // bands leave undecided take the exact divide-and-compare.
 template <int MODE, int U>
 __device__ __forceinline__ void suppress_words(const YpPrep &pi, bool row_ok, const float4 *cj,
-                                               const float *aj, const YpThr &thr, u64 *words)
+                                               const float *aj, const YpThr &thr, u64 *words,
+                                               unsigned int &ties)
 {
     const float plus1 = MODE == YP_MODE_YOLOV3 ? 1.0f : 0.0f;
     float lo0[U], lo1[U], hi0[U], hi1[U], d0[U], d1[U], inter[U], uni[U];
@@ -937,14 +952,17 @@ __device__ __forceinline__ void suppress_words(const YpPrep &pi, bool row_ok, co
         verdict[u] = v;
         undecided |= v;
     }
-    if (undecided & 2) {   // rare: some quotient sits within 2^-20 of the threshold
+    if (__any(undecided & 2)) {   // rare: some quotient sits within 2^-20 of the threshold
+        int nt = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            nt += __popcll(__ballot(verdict[u] == 2));
             if (verdict[u] == 2) {
                 const YpPrep pj = {cj[u].x, cj[u].y, cj[u].z, cj[u].w, aj[u]};
                 verdict[u] = yp_suppresses_exact<MODE>(pi, pj, thr.thr) ? 1 : 0;
             }
         }
+        ties += (threadIdx.x & 63) == 0 ? (unsigned int)nt : 0u;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) words[u] = __ballot(verdict[u] == 1);
@@ -954,8 +972,8 @@ template <int MODE, class Emit>
 __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *removed, int K,
                                           const YpThr thr, int max_out, ChunkShared &sh,
                                           float4 *xraw, int *xidx, bool prune,
-                                          unsigned int &pairs, unsigned long long *dbgseg,
-                                          Emit emit)
+                                          unsigned int &pairs, unsigned int &ties,
+                                          unsigned long long *dbgseg, Emit emit)
 {
 #ifdef YP_STAMPS
     unsigned long long acc[4] = {0, 0, 0, 0}, tprev = clock64();
@@ -1016,7 +1034,7 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
                     aj[u] = pr.area;
                 }
                 u64 words[4];
-                suppress_words<MODE, 4>(pc, col_ok, cj, aj, thr, words);
+                suppress_words<MODE, 4>(pc, col_ok, cj, aj, thr, words, ties);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) acc |= q0 + u < npend ? words[u] : 0ull;
             }
@@ -1048,7 +1066,7 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
                         aj[u] = pc.area;
                     }
                     u64 words[4];
-                    suppress_words<MODE, 4>(pi, row_ok, cj, aj, thr, words);
+                    suppress_words<MODE, 4>(pi, row_ok, cj, aj, thr, words, ties);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) mine = lane == 4 * part + u ? words[u] : mine;
                 }
@@ -1160,7 +1178,7 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
                                 aj[u] = pr.area;
                             }
                             u64 words[kColUnroll];
-                            suppress_words<MODE, kColUnroll>(pj, live, cj, aj, thr, words);
+                            suppress_words<MODE, kColUnroll>(pj, live, cj, aj, thr, words, ties);
 #pragma unroll
                             for (int u = 0; u < kColUnroll; ++u) drop |= q[u] >= 0 ? words[u] : 0ull;
                         }
@@ -1214,7 +1232,7 @@ void k_segment_nms(SegArgs s)
     __shared__ ChunkShared s_chunk;
     __shared__ int s_cnt[4];   // [0] candidates of lower classes, [1] of this class
     __shared__ int s_scan[kSegWaves];
-    __shared__ unsigned int s_pairs;
+    __shared__ unsigned int s_pairs, s_ties;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroups b and b + 8 share an XCD (and its L2): deal every XCD a contiguous run of
@@ -1236,6 +1254,7 @@ void k_segment_nms(SegArgs s)
 
     if (tid < 4) s_cnt[tid] = 0;
     if (tid == 0) s_pairs = 0u;
+    if (tid == 1) s_ties = 0u;
     STAMP(0);
 
     // ---- exclusive prefix of the image's tile counts: a kept row's position in the image's
@@ -1365,6 +1384,7 @@ void k_segment_nms(SegArgs s)
         if (tid == 0) {
             s.seg_kept[seg] = 0;
             s.seg_pairs[seg] = 0u;
+            s.seg_ties[seg] = 0u;
             if (MODE == YP_MODE_REFERENCE) {
                 s.out_counts[b] = 0;
                 s.surv_counts[b] = 0;
@@ -1374,7 +1394,7 @@ void k_segment_nms(SegArgs s)
     }
 
     const int max_out = s.max_out > 0 ? s.max_out : 0x7fffffff;
-    unsigned int pairs = 0;
+    unsigned int pairs = 0, ties = 0;
     int nkept = 0;
     const int *sslot_final;  // sorted position -> slot id, readable after the NMS loop
 
@@ -1484,14 +1504,20 @@ void k_segment_nms(SegArgs s)
                     verdict[u] = v;
                     undecided |= v;
                 }
-                if (undecided & 2) {   // rare: some quotient sits within 2^-20 of the threshold
+                if (__any(undecided & 2)) {   // rare: some quotient sits within 2^-20 of the threshold
+                    int nt = 0;
 #pragma unroll
                     for (int u = 0; u < kPairUnroll; ++u) {
+                        // (only the pairs of the triangle count: rows that precede the column)
+                        const int ju = j0 + u * kSegWaves, before_u = ju - (w << 6);
+                        const u64 rows_u = before_u >= 64 ? ~0ull : lanes_below(before_u);
+                        nt += ju < cend ? __popcll(__ballot(verdict[u] == 2 && i < K) & rows_u) : 0;
                         if (verdict[u] == 2) {
                             const YpPrep pj = {cj[u].x, cj[u].y, cj[u].z, cj[u].w, aj[u]};
                             verdict[u] = yp_suppresses_exact<MODE>(pi, pj, thr.thr) ? 1 : 0;
                         }
                     }
+                    ties += lane == 0 ? (unsigned int)nt : 0u;
                 }
                 // lane u stores the word of column u: one store instead of kPairUnroll
                 // single-lane ones
@@ -1736,7 +1762,7 @@ void k_segment_nms(SegArgs s)
         __syncthreads();
         const YpThr thr = yp_make_thr(s.thr);
         const bool prune = thr.fast && (MODE == YP_MODE_REFERENCE || allpos);
-        nkept = nms_chunks<MODE>(gbox, grem, K, thr, max_out, s_chunk, xraw, xidx, prune, pairs,
+        nkept = nms_chunks<MODE>(gbox, grem, K, thr, max_out, s_chunk, xraw, xidx, prune, pairs, ties,
 #ifdef YP_STAMPS
                                  s.dbg ? s.dbg + (size_t)blockIdx.x * 32 : nullptr,
 #else
@@ -1748,11 +1774,14 @@ void k_segment_nms(SegArgs s)
 
     STAMP(5);
     pairs = (unsigned int)wave_sum((int)pairs);
+    ties = (unsigned int)wave_sum((int)ties);
     if (lane == 0 && pairs) atomicAdd(&s_pairs, pairs);
+    if (lane == 0 && ties) atomicAdd(&s_ties, ties);
     __syncthreads();
     if (tid == 0) {
         s.seg_kept[seg] = nkept;
         s.seg_pairs[seg] = s_pairs;
+        s.seg_ties[seg] = s_ties;
         if (MODE == YP_MODE_REFERENCE) {
             s.out_counts[b] = nkept;
             s.surv_counts[b] = K;
@@ -1771,8 +1800,11 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_rows(GatherArgs g)
     __shared__ int s_part[kGatherThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = blockIdx.x;
+    // every set (independent batch) has its own output rows and count: the prefix runs over the
+    // earlier segments of this segment's set only
+    const int set = seg / g.spset, seg0 = set * g.spset;
     int part = 0;
-    for (int i = tid; i < seg; i += kGatherThreads) part += g.seg_kept[i];
+    for (int i = seg0 + tid; i < seg; i += kGatherThreads) part += g.seg_kept[i];
     part = wave_sum(part);
     int prefix = __shfl(part, 0, 64);   // wave_sum leaves the total in lane 0
     if (kGatherThreads > 64) {
@@ -1784,23 +1816,27 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_rows(GatherArgs g)
     }
     const int nk = g.seg_kept[seg];
     if (tid == 0) {
-        if (seg == g.n_seg - 1) g.out_count[0] = prefix + nk;
-        if (g.stats) {
-            g.stats[seg] = g.seg_cand[seg];
-            g.stats[g.n_seg + seg] = nk;
-            g.stats[2 * g.n_seg + seg] = (int)g.seg_pairs[seg];
+        if (seg == seg0 + g.spset - 1) g.out_count[set] = prefix + nk;
+        if (g.stats) {   // (n_sets, 4, images per set, C)
+            int *st = g.stats + (size_t)set * 4 * g.spset + (seg - seg0);
+            st[0] = g.seg_cand[seg];
+            st[g.spset] = nk;
+            st[2 * g.spset] = (int)g.seg_pairs[seg];
+            st[3 * g.spset] = (int)g.seg_ties[seg];
         }
     }
     const int b = seg / g.C, c = seg - b * g.C;
+    const int b_in_set = b - set * (g.spset / g.C);
     const size_t ibase = (size_t)b * g.spi;
     const size_t reg = ibase + g.seg_region[seg];
+    float *rows_out = g.out_rows + (size_t)set * g.set_stride;
     for (int k = tid; k < nk; k += kGatherThreads) {
         const long long d = (long long)prefix + k;
         if (d >= g.cap) break;
         const int slot = g.kept_slot[reg + k];
         const float4 bx = g.cand_box[ibase + slot];
-        float4 *o = reinterpret_cast<float4 *>(g.out_rows + d * 8);
-        o[0] = make_float4((float)(b + g.batch_offset), bx.x, bx.y, bx.z);
+        float4 *o = reinterpret_cast<float4 *>(rows_out + d * 8);
+        o[0] = make_float4((float)(b_in_set + g.batch_offset), bx.x, bx.y, bx.z);
         o[1] = make_float4(bx.w, g.cand_key[ibase + slot], g.cand_aux[ibase + slot], (float)c);
     }
 }
@@ -1932,6 +1968,7 @@ struct Workspace {
     int *seg_cand;
     int *seg_region;
     unsigned int *seg_pairs;
+    unsigned int *seg_ties;
 };
 
 template <class T>
@@ -1965,6 +2002,7 @@ size_t carve(void *base_v, size_t slots, size_t tiles, size_t n_seg, Workspace *
     off = carve_one(base, off, n_seg, &w->seg_cand);
     off = carve_one(base, off, n_seg, &w->seg_region);
     off = carve_one(base, off, n_seg, &w->seg_pairs);
+    off = carve_one(base, off, n_seg, &w->seg_ties);
     return (off + kAlign - 1) / kAlign * kAlign;
 }
 
@@ -1973,15 +2011,33 @@ bool params_ok(const YpParams *p, int mode)
     if (!p || p->mode != mode || p->batch <= 0 || p->batch > 65535) return false;
     if (p->num_classes <= 0 || p->num_classes > 4096) return false;
     if (!(p->nms_thr == p->nms_thr) || !(p->conf_thr == p->conf_thr)) return false;
+#ifndef YP_DIAG
+    if (p->reserved != 0) return false;   // (diagnostic builds read a stage mask here)
+#endif
     return true;
 }
 
 // Geometry of a set of YOLOv3 heads: tiles of cells_per_tile cells, slots per tile =
 // cells_per_tile * max anchors.
 int heads_geometry(const YpHead *heads, int n_heads, int C, int cells_per_tile, HeadsArgs *ha,
-                   int *amax_out)
+                   int *amax_out, int n_sets = 1)
 {
     if (!heads || n_heads < 1 || n_heads > YP_MAX_HEADS) return YP_ERR_ARG;
+    if (n_sets < 1 || n_sets > YP_MAX_SETS) return YP_ERR_UNSUPPORTED;
+    // sets are set-major in `heads`; every set must repeat the geometry of set 0
+    for (int s = 0; s < YP_MAX_SETS; ++s)
+        for (int i = 0; i < YP_MAX_HEADS; ++i) {
+            const bool used = s < n_sets && i < n_heads;
+            const YpHead &h = heads[used ? s * n_heads + i : 0], &h0 = heads[used ? i : 0];
+            if (used && (!h.data || h.grid_h != h0.grid_h || h.grid_w != h0.grid_w ||
+                         h.num_anchors != h0.num_anchors || h.stride_x != h0.stride_x ||
+                         h.stride_y != h0.stride_y))
+                return YP_ERR_ARG;
+            if (used)
+                for (int k = 0; k < 2 * YP_MAX_ANCHORS && k < 2 * h0.num_anchors; ++k)
+                    if (h.anchors[k] != h0.anchors[k]) return YP_ERR_ARG;
+            ha->data[s][i] = h.data;
+        }
     int amax = 0;
     long long tiles = 0, rows = 0;
     for (int i = 0; i < n_heads; ++i) {
@@ -2006,6 +2062,7 @@ int heads_geometry(const YpHead *heads, int n_heads, int C, int cells_per_tile, 
     for (int i = n_heads; i < YP_MAX_HEADS; ++i) ha->h[i] = ha->h[0];
     if (tiles > (1ll << 22) || rows > (1ll << 28)) return YP_ERR_UNSUPPORTED;
     ha->dbg = nullptr;
+    ha->bps = 0;   // set by the caller that launches a front kernel
     ha->n_heads = n_heads;
     ha->tpi = (int)tiles;
     ha->C = C;
@@ -2070,6 +2127,7 @@ SegArgs make_seg_args(const Workspace &w, const YpParams *p, int spi, int tpi, i
     s.seg_cand = w.seg_cand;
     s.seg_region = w.seg_region;
     s.seg_pairs = w.seg_pairs;
+    s.seg_ties = w.seg_ties;
     s.dbg = g_dbg;
     return s;
 }
@@ -2111,12 +2169,17 @@ inline void prof_next()
     } while (0)
 
 // Segment NMS + final gather of the YOLOv3 path (shared by the heads and rows entries).
-int finish_v3(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, float *out_rows,
-              long long cap, int32_t *out_count, int32_t *stats, hipStream_t st)
+int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tpi, int ts,
+              float *out_rows, long long cap, int32_t *out_count, int32_t *stats, hipStream_t st)
 {
-    const int n_seg = p->batch * p->num_classes;
-    const int stages = p->reserved ? p->reserved : 7;   // benchmarking: run a subset of the stages
+    const int n_seg = n_sets * p->batch * p->num_classes;
+#ifdef YP_DIAG
+    const int stages = p->reserved ? p->reserved : 7;   // diagnostic build: run a subset of the stages
+#else
+    const int stages = 7;
+#endif
     SegArgs s = make_seg_args(w, p, spi, tpi, ts, 1);
+    s.B = n_sets * p->batch;
     s.max_out = p->max_out;
     if (stages & 2)
         YP_LAUNCH(1, k_segment_nms<YP_MODE_YOLOV3>, dim3(n_seg), dim3(kSegThreads), 0, st, s);
@@ -2125,6 +2188,9 @@ int finish_v3(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, f
     g.C = p->num_classes;
     g.spi = spi;
     g.batch_offset = p->batch_offset;
+    g.spset = p->batch * p->num_classes;
+    g.set_stride = cap * 8;
+    g.seg_ties = w.seg_ties;
     g.cand_box = w.cand_box;
     g.cand_key = w.cand_key;
     g.cand_aux = w.cand_aux;
@@ -2164,7 +2230,7 @@ int finish_ref(const Workspace &w, const YpParams *p, int spi, int tpi, int ts, 
 
 extern "C" {
 
-int yp_version(void) { return 100; }
+int yp_version(void) { return 200; }
 
 const char *yp_strerror(int code)
 {
@@ -2241,36 +2307,49 @@ size_t yp_detect_yolov3_workspace_bytes(const YpHead *heads, int n_heads, int ba
                  (size_t)batch * num_classes, nullptr);
 }
 
-int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params, float *d_out_rows,
-                     int64_t out_cap, int32_t *d_out_count, int32_t *d_stats, void *d_workspace,
-                     size_t workspace_bytes, void *stream)
+// Shared body of yp_detect_yolov3 (one set) and yp_detect_yolov3_multi.
+static int detect_v3_sets(const YpHead *heads, int n_heads, int n_sets, const YpParams *params,
+                          float *d_out_rows, int64_t out_cap, int32_t *d_out_count,
+                          int32_t *d_stats, void *d_workspace, size_t workspace_bytes,
+                          void *stream)
 {
     if (!params_ok(params, YP_MODE_YOLOV3) || !d_out_rows || !d_out_count || out_cap < 0)
         return YP_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(d_out_rows) & 15) != 0) return YP_ERR_ARG;
+    if (n_sets < 1 || n_sets > YP_MAX_SETS) return YP_ERR_UNSUPPORTED;
+    if (n_sets > 1 && (out_cap & 1)) return YP_ERR_ARG;   // keeps every set's rows 16-byte aligned
     HeadsArgs ha;
     int amax = 0;
-    const int rc = heads_geometry(heads, n_heads, params->num_classes, kFrontCells, &ha, &amax);
+    const int rc = heads_geometry(heads, n_heads, params->num_classes, kFrontCells, &ha, &amax, n_sets);
     if (rc != YP_OK) return rc;
+    const long long images = (long long)n_sets * params->batch;
+    if (images > 65535) return YP_ERR_UNSUPPORTED;
     const int ts = kFrontCells * amax;
     const long long spi = (long long)ha.tpi * ts;
-    if (!slots_fit(params->batch, spi)) return YP_ERR_UNSUPPORTED;
-    const size_t slots = (size_t)params->batch * spi, tiles = (size_t)params->batch * ha.tpi;
-    const size_t n_seg = (size_t)params->batch * params->num_classes;
+    if (!slots_fit(images, spi)) return YP_ERR_UNSUPPORTED;
+    const size_t slots = (size_t)images * spi, tiles = (size_t)images * ha.tpi;
+    const size_t n_seg = (size_t)images * params->num_classes;
     Workspace w;
     const size_t need = carve(nullptr, slots, tiles, n_seg, nullptr);
     if (!workspace_ok(d_workspace, workspace_bytes, need)) return YP_ERR_WORKSPACE;
     carve(d_workspace, slots, tiles, n_seg, &w);
     CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, ha.tpi, ts};
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(ha.tpi, params->batch), block(kFrontCells * amax);
+    const dim3 grid(ha.tpi, params->batch, n_sets), block(kFrontCells * amax);
     float t_lo, t_hi;
     logit_band(params->conf_thr, &t_lo, &t_hi);
     ha.dbg = g_dbg_front;
+    ha.bps = params->batch;
     bool all_three = true;
     for (int i = 0; i < n_heads; ++i) all_three = all_three && heads[i].num_anchors == 3;
-    if (params->reserved && !(params->reserved & 1)) {
-        // benchmarking: the front stage is skipped (the workspace keeps the previous candidates)
+#ifdef YP_DIAG
+    const bool run_front = !params->reserved || (params->reserved & 1);
+#else
+    const bool run_front = true;
+#endif
+    if (!run_front) {
+        // diagnostic build, stage mask without the front stage: the workspace keeps the
+        // previous candidates
     } else if (params->num_classes == 5 && all_three)
         YP_LAUNCH(0, (k_front_heads_v3_wave<5, 3>), grid, dim3(64),
                   (size_t)kStageWin * ((6 + 5 + 3) & ~3) * sizeof(float), st, ha, cb, params->conf_thr, t_lo,
@@ -2281,7 +2360,25 @@ int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params, f
     else
         YP_LAUNCH(0, k_front_heads_v3<0>, grid, block, (size_t)ts * 6 * sizeof(float), st, ha, cb,
                   params->conf_thr, t_lo, t_hi);
-    return finish_v3(w, params, (int)spi, ha.tpi, ts, d_out_rows, out_cap, d_out_count, d_stats, st);
+    return finish_v3(w, params, n_sets, (int)spi, ha.tpi, ts, d_out_rows, out_cap, d_out_count,
+                     d_stats, st);
+}
+
+int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params, float *d_out_rows,
+                     int64_t out_cap, int32_t *d_out_count, int32_t *d_stats, void *d_workspace,
+                     size_t workspace_bytes, void *stream)
+{
+    return detect_v3_sets(heads, n_heads, 1, params, d_out_rows, out_cap, d_out_count, d_stats,
+                          d_workspace, workspace_bytes, stream);
+}
+
+int yp_detect_yolov3_multi(const YpHead *heads, int n_heads, int n_sets, const YpParams *params,
+                           float *d_out_rows, int64_t out_cap, int32_t *d_out_count,
+                           int32_t *d_stats, void *d_workspace, size_t workspace_bytes,
+                           void *stream)
+{
+    return detect_v3_sets(heads, n_heads, n_sets, params, d_out_rows, out_cap, d_out_count,
+                          d_stats, d_workspace, workspace_bytes, stream);
 }
 
 size_t yp_rows_workspace_bytes(int batch, int rows_per_image, int segments_per_image)
@@ -2326,8 +2423,8 @@ int yp_write_results(const float *d_rows, int rows_per_image, const YpParams *pa
     else
         YP_LAUNCH(0, k_front_rows_v3<false>, dim3(tpi, params->batch), dim3(kRowTile), 0, st, d_rows,
                   rows_per_image, params->num_classes, cb, params->conf_thr);
-    return finish_v3(w, params, (int)spi, tpi, kRowTile, d_out_rows, out_cap, d_out_count, d_stats,
-                     st);
+    return finish_v3(w, params, 1, (int)spi, tpi, kRowTile, d_out_rows, out_cap, d_out_count,
+                     d_stats, st);
 }
 
 static int ref_outputs_ok(const YpParams *p, const void *a, const void *b, const void *c,

@@ -100,6 +100,54 @@ class PaddedRowGather:
         return torch.cat([r[k, 1:1 + min(c, self.cap)] for k, c in enumerate(counts)], 0), counts
 
 
+class PaddedSetGather:
+    """``PaddedRowGather`` for the multi-set engine: the detection rows of up to ``n_sets``
+    batches (one launch of ``YoloV3PostMulti``) leave in ONE all_gather_into_tensor.
+
+    ``send`` is (1 + n_sets * cap, W): row 0 is a header whose first ``n_sets`` elements carry
+    the per-set row counts (float32, exact below 2**24), then ``n_sets`` slabs of ``cap`` rows
+    (``rows`` is that (n_sets, cap, W) view: hand it to the engine as its output).  ``gather``
+    enqueues the collective behind whatever the current stream holds and returns without a host
+    synchronisation when the backend is nccl (RCCL); nothing is allocated per call."""
+
+    def __init__(self, n_sets, cap_rows, width, device, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        if not 0 < n_sets <= width:
+            raise ValueError("the header row holds one count per set: n_sets <= width")
+        if not 0 < cap_rows < (1 << 24):
+            raise ValueError("cap_rows must be in (0, 2**24)")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.n_sets, self.cap, self.width = int(n_sets), int(cap_rows), int(width)
+        n = 1 + self.n_sets * self.cap
+        self.send = torch.zeros((n, self.width), dtype=torch.float32, device=device)
+        self.recv = torch.zeros((self.world * n, self.width), dtype=torch.float32, device=device)
+
+    @property
+    def rows(self):
+        return self.send[1:].view(self.n_sets, self.cap, self.width)
+
+    def gather(self, counts, n_used=None):
+        """counts: (n_sets,) numeric tensor on the buffer's device; only the first ``n_used``
+        sets (default all) were produced by the launch this gather follows."""
+        n = self.n_sets if n_used is None else int(n_used)
+        if n < self.n_sets:
+            self.send[0].zero_()
+        self.send[0, :n].copy_(counts.reshape(-1)[:n])
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+
+    def unpack(self):
+        """[[rows of set s of rank r for s] for r] and the (world, n_sets) true counts (rows a
+        rank produced beyond ``cap`` were never sent)."""
+        r = self.recv.view(self.world, 1 + self.n_sets * self.cap, self.width)
+        counts = r[:, 0, :self.n_sets].to(torch.int64).tolist()
+        body = r[:, 1:].view(self.world, self.n_sets, self.cap, self.width)
+        rows = [[body[k, s, :min(int(c), self.cap)] for s, c in enumerate(counts[k])]
+                for k in range(self.world)]
+        return rows, [[int(c) for c in row] for row in counts]
+
+
 class ShardedYoloV3Post:
     """One rank's share of a global batch: a ``YoloV3Post`` over the rank's slice whose
     image indices are offset to global numbering, plus the final all-gather.  The gathered

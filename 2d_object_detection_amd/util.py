@@ -59,6 +59,12 @@ def predict_transform_heads(heads, inp_dim, anchors_per_head, num_classes):
         raise ValueError("1..%d heads supported" % _lib.YP_MAX_HEADS)
     dev = heads[0].device
     B = heads[0].shape[0]
+    for i, h in enumerate(heads):
+        if h.dim() != 4 or h.shape[0] != B:
+            raise ValueError("heads[%d] has shape %r: every head must be (B, A*(5+C), gh, gw) "
+                             "with the same batch B = %d" % (i, tuple(h.shape), B))
+        if h.device != dev:
+            raise ValueError("heads[%d] is on %s, heads[0] on %s" % (i, h.device, dev))
     descs = (_lib.YpHead * len(heads))(
         *[_head_desc(h, inp_dim, a, num_classes) for h, a in zip(heads, anchors_per_head)])
     N = sum(d.grid_h * d.grid_w * d.num_anchors for d in descs)
@@ -96,7 +102,8 @@ def write_results_device(prediction, confidence, num_classes, nms_conf=0.4, out_
     cap = B * N if out_cap is None else int(out_cap)
     out = torch.empty((max(cap, 1), 8), dtype=torch.float32, device=dev)
     count = torch.zeros((1,), dtype=torch.int32, device=dev)
-    stats = torch.zeros((3, B, num_classes), dtype=torch.int32, device=dev) if want_stats else None
+    stats = (torch.zeros((_lib.YP_STATS_PLANES, B, num_classes), dtype=torch.int32, device=dev)
+             if want_stats else None)
     if B == 0 or N == 0:
         return out, count, stats
     L = _lib.load()
@@ -185,8 +192,8 @@ class YoloV3Post:
             self.cap = self.batch * self.rows_per_image if out_cap is None else int(out_cap)
             self.out = torch.empty((max(self.cap, 1), 8), dtype=torch.float32, device=self.device)
         self.count = torch.zeros((1,), dtype=torch.int32, device=self.device)
-        self.stats = torch.zeros((3, self.batch, self.num_classes), dtype=torch.int32,
-                                 device=self.device)
+        self.stats = torch.zeros((_lib.YP_STATS_PLANES, self.batch, self.num_classes),
+                                 dtype=torch.int32, device=self.device)
         # everything the per-batch call needs, resolved once
         self._desc_cache = {}
         self._detect = self._lib.yp_detect_yolov3
@@ -214,9 +221,11 @@ class YoloV3Post:
         """Enqueue decode + filter + NMS; returns (rows (cap, 8), count (1,) int32) on the
         device.  rows[:count] are valid once the stream has executed.  ``stream`` is a
         torch.cuda.Stream (default: the current stream).  The validated head descriptors
-        are cached per set of input buffers, so a serving loop that reuses its input buffers
-        pays one C call per batch."""
-        key = tuple(h.data_ptr() for h in heads)
+        are cached per set of input buffers -- keyed on address, shape, strides, dtype and
+        device of every head, so a view of a cached buffer with another shape (a final
+        partial batch ``buf[:n]``) is validated afresh and rejected -- and a serving loop that
+        reuses its input buffers pays one C call per batch."""
+        key = tuple((h.data_ptr(), h.shape, h.stride(), h.dtype, h.device) for h in heads)
         descs = self._desc_cache.get(key)
         if descs is None:
             descs = self._descs(heads)
@@ -241,3 +250,100 @@ class YoloV3Post:
         """(survivors, kept, iou_pairs) per (image, class) of the last run, int32 (B, C)."""
         s = self.stats.cpu().numpy()
         return s[0], s[1], s[2]
+
+    def tie_stats(self):
+        """Per (image, class) of the last run, int32 (B, C): how many of the evaluated IoU pairs
+        lay within 2**-20 (relative) of the NMS threshold -- the IoU-at-threshold ties, which
+        the kernel decides with the exact divide-and-compare."""
+        return self.stats[3].cpu().numpy()
+
+
+class YoloV3PostMulti:
+    """``n_sets`` independent batches of one configuration per call: ONE launch per stage for
+    all of them (yp_detect_yolov3_multi).  ``run`` takes a list of ``n_sets`` head lists and
+    returns (rows (n_sets, cap, 8), counts (n_sets,) int32) on the device; set s's detections
+    are rows[s, :counts[s]] and equal what ``YoloV3Post.run`` gives for that batch alone."""
+
+    def __init__(self, n_sets, batch, inp_dim, num_classes=5, confidence=0.5, nms_conf=0.4,
+                 anchors=YOLOV3_ANCHORS, strides=(32, 16, 8), device=None, out_cap=None,
+                 batch_offset=0, out=None):
+        if not 1 <= int(n_sets) <= _lib.YP_MAX_SETS:
+            raise ValueError("1..%d sets per call" % _lib.YP_MAX_SETS)
+        self.n_sets = int(n_sets)
+        # geometry, validation and parameters are those of a single-set engine; its own
+        # buffers are sized for one image and unused
+        self._one = YoloV3Post(batch, inp_dim, num_classes, confidence, nms_conf, anchors, strides,
+                               device, out_cap=2, batch_offset=batch_offset)
+        o = self._one
+        self.device, self.batch, self.num_classes = o.device, o.batch, o.num_classes
+        self.grids, self.rows_per_image, self.params = o.grids, o.rows_per_image, o.params
+        self._lib = _lib.load()
+        in_h, in_w = _dims(inp_dim)
+        shape_only = (_lib.YpHead * len(self.grids))(*[
+            _lib.make_head(None, gh, gw, _scaled_anchors(a, in_w // gw, in_h // gh),
+                           in_w // gw, in_h // gh)
+            for (gh, gw), a in zip(self.grids, anchors)])
+        nbytes = self._lib.yp_detect_yolov3_workspace_bytes(shape_only, len(self.grids),
+                                                            self.n_sets * self.batch, self.num_classes)
+        if nbytes == 0:
+            raise _lib.YoloPostError("unsupported head geometry")
+        self.workspace = _lib.workspace(nbytes, self.device)
+        if out is not None:
+            # caller-provided output rows (e.g. the payload view of a gather buffer)
+            _lib.require_device(out, "out")
+            if (out.dtype != torch.float32 or out.dim() != 3 or out.shape[0] != self.n_sets
+                    or out.shape[2] != 8 or not out.is_contiguous() or out.data_ptr() % 16
+                    or (out.shape[1] & 1 and self.n_sets > 1)):
+                raise ValueError("out must be a contiguous 16-byte aligned float32 "
+                                 "(n_sets, even cap, 8) tensor")
+            self.cap, self.out = out.shape[1], out
+        else:
+            cap = self.batch * self.rows_per_image if out_cap is None else int(out_cap)
+            self.cap = cap + (cap & 1)     # even: every set's rows start 16-byte aligned
+            self.out = torch.empty((self.n_sets, max(self.cap, 2), 8), dtype=torch.float32,
+                                   device=self.device)
+        self.count = torch.zeros((self.n_sets,), dtype=torch.int32, device=self.device)
+        self.stats = torch.zeros((self.n_sets, _lib.YP_STATS_PLANES, self.batch, self.num_classes),
+                                 dtype=torch.int32, device=self.device)
+        self._desc_cache = {}
+
+    def _descs(self, sets, n):
+        if not 1 <= n <= self.n_sets:
+            raise ValueError("expected 1..%d sets of heads, got %d" % (self.n_sets, n))
+        flat = []
+        for heads in sets:
+            flat.extend(self._one._descs(heads))     # validates every head of every set
+        return (_lib.YpHead * len(flat))(*flat)
+
+    def run(self, sets, stream=None):
+        """sets: 1..n_sets lists of heads (fewer than n_sets uses the first len(sets) slices
+        of the outputs).  Returns (rows, counts) on the device."""
+        n = len(sets)
+        key = tuple((h.data_ptr(), h.shape, h.stride(), h.dtype, h.device) for heads in sets
+                    for h in heads)
+        descs = self._desc_cache.get(key)
+        if descs is None:
+            descs = self._descs(sets, n)
+            if len(self._desc_cache) > 64:
+                self._desc_cache.clear()
+            self._desc_cache[key] = descs
+        stream = _lib.stream_ptr(self.device) if stream is None else stream.cuda_stream
+        with _lib.on_device(self.device):
+            rc = self._lib.yp_detect_yolov3_multi(
+                descs, len(self.grids), n, ctypes.byref(self.params), self.out.data_ptr(), self.cap,
+                self.count.data_ptr(), self.stats.data_ptr(), self.workspace.data_ptr(),
+                self.workspace.numel(), stream)
+        if rc != 0:
+            _lib.check(rc, "yp_detect_yolov3_multi")
+        return self.out, self.count
+
+    def detect(self, sets):
+        """run() + one host read of the counts: a list of (D_s, 8) detections, one per set."""
+        out, count = self.run(sets)
+        c = count.cpu().tolist()
+        return [out[s, :min(int(c[s]), self.cap)] for s in range(len(sets))]
+
+    def segment_stats(self, n=None):
+        """(survivors, kept, iou_pairs, ties), each int32 (n_sets, B, C), of the last run."""
+        s = self.stats.cpu().numpy()
+        return s[:, 0], s[:, 1], s[:, 2], s[:, 3]

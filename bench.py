@@ -3,35 +3,47 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg1|cfg3|cfg4|cfg5]
 
-One "step" = one pass of the fused path (three HIP kernels through the C ABI of
-libyolopost.so) over one batch of synthetic raw detection heads that are already resident
-in HBM.  At N=1 the default workload is BASELINE.json's configs[1]: batch 64 at 416x416,
-three YOLOv3 heads x 3 anchors, 5 classes, conf 0.5 / NMS 0.4.  With N>1 (launched by
-torch.distributed.run, one rank per GPU) every rank processes its own batch of the same size
-(weak scaling).  Images are independent, so a step needs no collective; the ranks exchange
-their variable-length detection lists with one RCCL all-gather at the end (--exchange final,
-the default; one untimed exchange beforehand warms the collective up) or, opt-in and
-experimental, after every step (--exchange every-step, overlapped with the next steps; at
-4 M images/s per GPU that is ~100 GB/s of rows per rank to replicate everywhere, more than
-xGMI carries, so that mode is communication-bound by construction).
+One "step" = one pass of the fused path over one batch of synthetic raw detection heads that
+are already resident in HBM.  At N=1 the default workload is BASELINE.json's configs[1]: batch
+64 at 416x416, three YOLOv3 heads x 3 anchors, 5 classes, conf 0.5 / NMS 0.4.
+
+How the steps are issued.  Consecutive batches are independent, so S of them (default 4) go to
+the GPU together as ONE launch per stage (yp_detect_yolov3_multi), alternating between F
+engines on F HIP streams (default 2) so that the HBM-bound front kernel of one launch overlaps
+the issue-bound NMS kernel of the other.  K steps are ceil(K/S) launches.
+
+What the steps read.  The timed loop cycles through R distinct input sets with R x bytes per
+batch >= 512 MiB (20 sets at cfg2), twice the 256 MiB Infinity Cache, so every batch is read
+from HBM and not from the cache; the cache-resident figure stands beside it as
+roofline.frac_cache_resident.
+
+Timing.  The K-step timed region -- bracketed by a barrier (N > 1) and a device
+synchronisation on both sides -- is repeated --repeats times in one run; ms_per_step and value
+are the MEDIAN repeat (min and max beside them), the maximum over ranks of each repeat.
+
+With N>1 (launched by torch.distributed.run, one rank per GPU) every rank processes its own
+batches of the same size (weak scaling).  Images are independent, so the kernels need no
+collective; the ranks exchange their variable-length detection lists with one fixed-capacity
+RCCL all-gather per launch (i.e. every batch's rows reach every rank), enqueued behind the
+launch's kernels on its stream.  `value` includes that exchange; `value_no_exchange` is the
+same loop without it.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      the front kernel (decode + filter + compaction), algorithmic bytes
-                40*B*N read + 28*sum(K) + 4*tiles written, divided by its HIP-event time
-  cpu_baseline  the CPU oracle (oracle/ypo.c, a single-threaded port of the same path)
-                timed on this host on the same workload
+  roofline      the front kernel (decode + filter + compaction): algorithmic bytes per launch
+                S x (40*B*N read + 28*sum(K) + 4*tiles written) / its HIP-event time
+  cpu_baseline  the CPU oracle (oracle/ypo.c, a C port of the same path) timed on this host on
+                the same workload, on one core and on all cores the box gives the process
 """
 import argparse
 import importlib
 import json
 import os
+import statistics
 import sys
 import time
 
-# HIP gives a process 4 hardware queues by default, one of which serves the null stream, so at
-# most 3 streams run concurrently; the path is fastest with 4 batches in flight on 4 queues of
-# their own.  Must be set before the HIP runtime initialises.  (YP_HW_QUEUES overrides.)
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("YP_HW_QUEUES", "8")
+if os.environ.get("YP_HW_QUEUES"):   # optional experiment knob; the default run needs no setting
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["YP_HW_QUEUES"]
 
 import numpy as np
 import torch
@@ -48,13 +60,14 @@ CONFIGS = {
     "cfg3": (32, (1280, 1920), 0.5, 0.4, 2,
              "batch 32 at 1920x1280 (151,200 anchors/image), conf 0.5 / NMS 0.4"),
     "cfg3x2": (64, (1280, 1920), 0.5, 0.4, 2,
-               "batch 64 at 1920x1280 (387 MB of heads, larger than the 256 MiB Infinity Cache)"),
+               "batch 64 at 1920x1280 (387 MB of heads per batch)"),
     "cfg4": (64, 608, 0.5, 0.4, 3, "batch 64 per GPU at 608x608 (22,743 anchors/image), conf 0.5 / NMS 0.4"),
     "cfg5": (32, (1280, 1920), 0.001, 0.4, 4,
              "batch 32 per GPU at 1920x1280, conf 0.001 / NMS 0.4 (near-all survive)"),
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak
 NUM_CLASSES = 5
+CYCLE_BYTES = 512 << 20  # distinct input bytes the timed loop cycles through (2 x Infinity Cache)
 
 
 def make_device_heads(batch, inp_dim, seed, dev, clustered):
@@ -67,47 +80,61 @@ def make_device_heads(batch, inp_dim, seed, dev, clustered):
     return cpu, [h.to(dev) for h in cpu]
 
 
-def front_kernel_roofline(config_name, dev, launches=30):
-    """The front kernel timed alone (start/stop HIP events attached to each launch) on another
-    configuration's shape: same kernel, same accounting as the headline's roofline object."""
-    batch, inp_dim, conf, nms, seed, desc = CONFIGS[config_name]
-    _, hs = make_device_heads(batch, inp_dim, seed, dev, False)
-    eng = util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev)
-    for _ in range(3):
-        eng.run(hs)
-    _lib.profile_start(launches)
-    for _ in range(launches):
-        eng.run(hs)
-    front_ms, _, _, calls = _lib.profile_stop()
-    torch.cuda.synchronize()
-    surv, _, _ = eng.segment_stats()
-    n_anchors = batch * syn.anchors_per_image(inp_dim if isinstance(inp_dim, int) else tuple(inp_dim))
-    tiles = batch * sum(-(-(gh * gw) // 128) for gh, gw in eng.grids)
-    alg = 40.0 * n_anchors + 28.0 * int(surv.sum()) + 4.0 * tiles
-    achieved = alg / (front_ms * 1e-3) / 1e9
-    return {"workload": "%s: %s" % (config_name, desc), "bound": "hbm", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "algorithmic_bytes": int(alg), "kernel_ms": round(front_ms, 5), "launches": calls,
-            "regime": "one batch at a time on one stream (as frac_alone)"}
+def make_input_sets(base, n_sets):
+    """n_sets distinct device copies of one batch: copy k holds the same images rotated by k
+    positions along the batch axis, so every copy is a batch of the same statistics at its own
+    addresses (what the caches see), generated without n_sets host uploads."""
+    sets = [base]
+    B = base[0].shape[0]
+    for k in range(1, n_sets):
+        sets.append([torch.roll(h, k % B, 0).contiguous() if B > 1 else h.clone() for h in base])
+    return sets
 
 
 def cpu_baseline(cpu_heads, inp_dim, conf, nms, budget_s=10.0):
-    """The CPU oracle on the same workload, single thread; repeats until ~budget_s."""
+    """The CPU oracle on the same workload: one core, then all cores the process may use (one
+    thread per core, each repeating the oracle on its own share of the images; the C functions
+    run without the interpreter lock).  About budget_s seconds of wall time in total."""
     import oracle
+    from concurrent.futures import ThreadPoolExecutor
     hs = [h.numpy() for h in cpu_heads]
     B = hs[0].shape[0]
     sample = min(B, 64)
-    hs = [h[:sample] for h in hs]
+    hs = [np.ascontiguousarray(h[:sample]) for h in hs]
+
+    def run(sub):
+        oracle.n_detect(sub, inp_dim, syn.YOLOV3_ANCHORS, NUM_CLASSES, conf, nms)
+
     reps, t0 = 0, time.perf_counter()
     while True:
-        oracle.n_detect(hs, inp_dim, syn.YOLOV3_ANCHORS, NUM_CLASSES, conf, nms)
+        run(hs)
         reps += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 200:
+        if el >= budget_s * 0.6 or reps >= 200:
             break
-    return {"value": round(sample * reps / el, 2), "unit": "images/s", "cores": 1, "kind": "port",
-            "sample": "%d images of the same workload x %d repetitions (%.1f s), oracle/ypo.c "
-                      "single thread" % (sample, reps, el)}
+    one = sample * reps / el
+
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(avail, int(os.environ.get("OMP_NUM_THREADS", avail)), sample))
+    shares = [[np.ascontiguousarray(h[w::cores]) for h in hs] for w in range(cores)]
+    deadline = budget_s * 0.4
+
+    def worker(sub):
+        n, t = 0, time.perf_counter()
+        while True:
+            run(sub)
+            n += sub[0].shape[0]
+            if time.perf_counter() - t >= deadline:
+                return n
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(worker, shares))
+    el_all = time.perf_counter() - t0
+    return {"value": round(done / el_all, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "value_1core": round(one, 2), "host_cpus": os.cpu_count(),
+            "sample": "%d images of the same workload: x %d repetitions on 1 core (%.1f s), then shared "
+                      "over %d threads of oracle/ypo.c for %.1f s (%d images done)"
+                      % (sample, reps, el, cores, el_all, done)}
 
 
 def side_workload(args):
@@ -153,28 +180,31 @@ def side_workload(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="how often the K-step timed region is repeated (median reported); "
+                         "0 = 30, fewer when K x 30 exceeds 6000 steps")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--clustered", action="store_true",
                     help="overlapping boxes around object centres instead of i.i.d. boxes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0,
-                    help="CPU work spent on the cpu_baseline leg (N = 1 only)")
-    ap.add_argument("--exchange", default="final", choices=["final", "every-step"],
-                    help="N > 1: when the ranks exchange detection rows (see timed_run)")
+                    help="wall time spent on the cpu_baseline leg (N = 1 only)")
     ap.add_argument("--workload", default="detect",
                     choices=["detect", "reference", "grid_codec", "train_kernels"],
-                    help="detect = the headline path (default); reference = the reference's own 13x13 configuration; "
-                         "the others time the label-side and "
-                         "training-side kernels and print one JSON line per kernel")
-    ap.add_argument("--in-flight", type=int, default=0,
-                    help="independent batches in flight (engines x HIP streams); 1 = latency mode; "
-                         "0 (default) = 3 or 4, whichever a short untimed probe finds faster here")
-    ap.add_argument("--no-large-input", action="store_true",
-                    help="skip the extra front-kernel measurement at the cfg3 shape")
-    ap.add_argument("--also-other-exchange", action="store_true",
-                    help="N > 1: also time the exchange schedule that was not selected, on a short loop")
+                    help="detect = the headline path (default); reference = the reference's own 13x13 "
+                         "configuration; the others time the label-side and training-side kernels and "
+                         "print one JSON line per kernel")
+    ap.add_argument("--sets-per-launch", type=int, default=0,
+                    help="independent batches handed to the GPU as one launch per stage (1..8); "
+                         "0 = 4, or 1 for batches above 64 MB")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="engines x HIP streams the launches alternate between")
+    ap.add_argument("--cycle-mib", type=int, default=CYCLE_BYTES >> 20,
+                    help="distinct input bytes the timed loop cycles through")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="N > 1: leave the detection rows sharded (no all-gather at all)")
     args = ap.parse_args()
     if args.workload != "detect":
         return side_workload(args)
@@ -186,7 +216,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal on a single GPU: take the multi-rank code path (process group, barriers, final
+    # rehearsal on a single GPU: take the multi-rank code path (process group, barriers,
     # exchange) with a world of one rank
     multi = world > 1 or os.environ.get("YP_BENCH_FORCE_DIST") == "1"
     if world != args.gpus:
@@ -207,216 +237,191 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    exchange = multi and not args.no_exchange
 
     batch, inp_dim, conf, nms, seed, desc = CONFIGS[args.config]
-    cpu_heads, heads = make_device_heads(batch, inp_dim, seed + 100 * rank, dev, args.clustered)
+    cpu_heads, base = make_device_heads(batch, inp_dim, seed + 100 * rank, dev, args.clustered)
     rows_per_image = syn.anchors_per_image(inp_dim if isinstance(inp_dim, int) else tuple(inp_dim))
-
-    # n_eng engines (own workspace and output buffers), each on its own HIP stream: consecutive
-    # batches are independent, so the decode of batch i+1 overlaps the NMS of batch i.
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(4, args.in_flight))]
-
-    def probe(n, steps=150):
-        """Local steps per second with n batches in flight (untimed calibration)."""
-        engs = [util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev) for _ in range(n)]
-        for i in range(30):
-            engs[i % n].run(heads, streams[i % n])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            engs[i % n].run(heads, streams[i % n])
-        torch.cuda.synchronize()
-        return steps / (time.perf_counter() - t0)
-
-    if args.in_flight > 0:
-        n_eng = args.in_flight
-    else:
-        rates = {n: probe(n) for n in (3, 4)}
-        n_eng = max(rates, key=rates.get)
+    batch_bytes = sum(h.numel() * 4 for h in base)
+    K, W = args.steps, args.warmup
+    S = args.sets_per_launch or (4 if batch_bytes <= (64 << 20) else 1)
+    S = max(1, min(S, _lib.YP_MAX_SETS, K))
+    F = max(1, args.in_flight)       # the same on every rank: the ranks issue identical sequences
+    # R distinct input sets, a multiple of S so that the launches see a handful of fixed groups
+    R = max(S, -(-(args.cycle_mib << 20) // batch_bytes))
+    # (at most 48 launch groups, which the engines' descriptor cache holds: tiny batches such as
+    # cfg1's single image then cycle through less than the Infinity Cache)
+    R = min(-(-R // S) * S, max(S, (16 << 30) // batch_bytes // S * S), 48 * S)
+    input_sets = make_input_sets(base, R)
+    repeats = args.repeats or max(3, min(30, 6000 // max(K, 1)))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
 
     def fence():
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run(exchange, steps, warmup):
-        """K steps of the path on this rank's batches.  exchange (N > 1 only):
-        "final"      detections stay sharded by image while the steps run; the ranks exchange the
-                     variable-length detection list of the last batch with one all-gather at the
-                     end of the timed region
-        "every-step" one fixed-capacity all-gather of every rank's rows after every step, enqueued
-                     behind the kernels and overlapped with the following steps"""
-        gathers, engines = [], []
-        per_step = multi and exchange == "every-step"
+    def make_engines(with_exchange, cap=None):
+        engines, gathers = [], []
+        for _ in range(F):
+            if with_exchange:   # the engine writes straight into the payload of its gather buffer
+                g = dsb.PaddedSetGather(S, cap, 8, dev)
+                gathers.append(g)
+                engines.append(util.YoloV3PostMulti(S, batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
+                                                    batch_offset=rank * batch, out=g.rows))
+            else:
+                engines.append(util.YoloV3PostMulti(S, batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
+                                                    batch_offset=rank * batch))
+        return engines, gathers
 
-        def build(gather_cap):
-            gathers.clear()
-            engines.clear()
-            for _ in range(n_eng):
-                if per_step:   # the engine writes straight into the payload of its gather buffer
-                    g = dsb.PaddedRowGather(gather_cap, 8, dev)     # rows of 32 B
-                    gathers.append(g)
-                    engines.append(util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
-                                                   batch_offset=rank * batch, out=g.rows))
-                else:
-                    engines.append(util.YoloV3Post(batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
-                                                   batch_offset=rank * batch))
+    def launch_plan(steps):
+        """[(first set index, sets in the launch)] for `steps` steps."""
+        plan, i = [], 0
+        while i < steps:
+            n = min(S, steps - i)
+            plan.append((i % R, n))
+            i += n
+        return plan
 
-        gather_cap = batch * 2048
-        build(gather_cap)
-        if per_step:
-            # size the fixed-capacity exchange from one real batch: largest per-rank detection
-            # count over all ranks + 25 %, so the collective moves little more than the payload
-            _, cnt = engines[0].run(heads)
+    def run_plan(plan, engines, gathers, j0=0):
+        for j, (first, n) in enumerate(plan, j0):
+            k = j % F
+            sets = [input_sets[(first + t) % R] for t in range(n)]
+            _, count = engines[k].run(sets, streams[k])
+            if gathers:
+                # one all-gather of the launch's rows, enqueued behind its kernels on its stream;
+                # no Work object is kept and nothing waits on the host (RCCL orders the collectives
+                # of the F streams on its own stream, in the issue order every rank shares)
+                with torch.cuda.stream(streams[k]):
+                    gathers[k].gather(count, n)
+        return j0 + len(plan)
+
+    def timed(engines, gathers):
+        """`repeats` timed regions of exactly K steps each; returns the per-repeat seconds
+        (maximum over ranks) and the host time spent enqueueing one region."""
+        plan = launch_plan(K)
+        j = run_plan(launch_plan(W), engines, gathers) if W > 0 else 0
+        fence()
+        times, t_enq = [], []
+        for _ in range(repeats):
+            fence()
+            t0 = time.perf_counter()
+            j = run_plan(plan, engines, gathers, j)
+            t1 = time.perf_counter()
             torch.cuda.synchronize()
-            cmax = cnt.to(torch.int64).clone()
-            dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
-            gather_cap = max(1024, -(-int(cmax.item()) * 5 // 4 // 1024) * 1024)
-            build(gather_cap)
-        pending = [None] * n_eng
-        last = [None]
+            el = time.perf_counter() - t0
+            if multi:
+                # closing bracket: the slowest rank's time for its K steps (this all-reduce is
+                # also the barrier every rank passes before the next region starts)
+                t = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            times.append(el)
+            t_enq.append(t1 - t0)
+        return times, statistics.median(t_enq)
+
+    # ---- the timed runs
+    xinfo = {}
+    engines, gathers = make_engines(False)
+    if exchange:
+        # size the fixed-capacity exchange from one real launch: largest per-set detection count
+        # over all ranks + 25 %, so the collective moves little more than the payload
+        run_plan(launch_plan(S), engines, [])
         torch.cuda.synchronize()
+        cmax = engines[0].count.to(torch.int64).max().reshape(1).clone()
+        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+        cap = max(1024, -(-int(cmax.item()) * 5 // 4 // 1024) * 1024)
+        times_nx, _ = timed(engines, [])
+        engines_x, gathers = make_engines(True, cap)
+        times, t_enq = timed(engines_x, gathers)
+        torch.cuda.synchronize()
+        _, counts = gathers[(len(launch_plan(W)) + repeats * len(launch_plan(K)) - 1) % F].unpack()
+        xinfo = {"exchange": "one fixed-capacity RCCL all-gather of every rank's detection rows per launch "
+                             "(%d batches), enqueued behind the launch's kernels on its stream" % S,
+                 "gather_rows_capacity_per_set": cap,
+                 "gather_bytes_per_rank_per_launch": (1 + S * cap) * 32,
+                 "gather_rows_last_launch": counts,
+                 "gather_overflow": bool(max(max(c) for c in counts) > cap)}
+        del engines_x
+    else:
+        times, t_enq = timed(engines, [])
+        times_nx = None
+    med = statistics.median(times)
 
-        def step(i):
-            k = i % n_eng
-            if not per_step:
-                last[0] = engines[k].run(heads, streams[k])
-                return
-            with torch.cuda.stream(streams[k]):
-                if pending[k] is not None:
-                    pending[k].wait()                # stream-level wait: buffer k is free again
-                    pending[k] = None
-                _, count = engines[k].run(heads, streams[k])
-                pending[k] = gathers[k].gather(count, async_op=True)
-
-        def drain():
-            for k in range(n_eng):
-                if pending[k] is not None:
-                    with torch.cuda.stream(streams[k]):
-                        pending[k].wait()
-                    pending[k] = None
-
-        for i in range(warmup):
-            step(i)
-        drain()
-        if multi and not per_step:
-            # the exchange is warmed up like the kernels, with a real batch's detection list: the
-            # first RCCL collective of a given size class costs 30-130 ms (measured,
-            # tools/exp_exchange_cost.py), later ones 0.2-0.3 ms
-            if last[0] is None:
-                last[0] = engines[0].run(heads, streams[0])
-            for _ in range(2):
-                with torch.cuda.stream(streams[0]):
-                    streams[0].wait_stream(torch.cuda.current_stream(dev))
-                    torch.cuda.synchronize()
-                    dsb.all_gather_rows(last[0][0], last[0][1])
-        fence()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
-        t_enqueued = time.perf_counter() - t0
-        drain()
-        info = {}
-        if multi and not per_step:
-            rows, count = last[0]
-            with torch.cuda.stream(streams[(steps - 1) % n_eng]):   # behind the last batch's kernels
-                gathered, counts = dsb.all_gather_rows(rows, count)
-            info = {"gather_rows_last_step": counts, "gathered_rows": int(gathered.shape[0])}
-        fence()
-        elapsed = time.perf_counter() - t0
-        if multi:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        if per_step:
-            gathered, counts = gathers[(steps - 1) % n_eng].unpack()
-            assert len(counts) == world
-            info = {"gather_rows_capacity_per_rank": gather_cap, "gather_rows_last_step": counts,
-                    "gather_overflow": bool(max(counts) > gather_cap)}
-            dist.barrier()
-        return elapsed, t_enqueued, engines, info
-
-    elapsed, t_enqueued, engines, xinfo = timed_run(args.exchange, args.steps, args.warmup)
-    other = None
-    if multi and args.also_other_exchange:
-        # the other exchange mode on a shorter loop, reported next to the headline
-        other_mode = "every-step" if args.exchange == "final" else "final"
-        o_steps = max(10, min(args.steps, 60))
-        o_el, _, _, o_info = timed_run(other_mode, o_steps, min(args.warmup, 5))
-        other = {"exchange": other_mode, "steps": o_steps,
-                 "images_per_s": round(world * batch * o_steps / o_el, 1)}
-        other.update({k: v for k, v in o_info.items() if k != "gather_rows_last_step"})
-
-    # per-kernel execution times: each launch carries its own start/stop HIP events on the launch
-    # stream (separate pass so the event bookkeeping does not perturb the throughput above)
-    nprof = max(10, min(args.steps, 200))
-    # (a) in the regime of the timed region: the same engines and streams, batches in flight
-    for i in range(4 * len(engines)):
-        engines[i % len(engines)].run(heads, streams[i % len(engines)])
+    # ---- per-kernel execution times: each launch carries its own start/stop HIP events on the
+    # launch stream (separate passes so the event bookkeeping does not perturb the loop above)
+    plan = launch_plan(max(K, 4 * S * F))
+    nprof = min(len(plan), 64)
+    plan = plan[:nprof]
+    # (a) in the regime of the timed region: F streams, inputs cycling through HBM
+    j = run_plan(plan, engines, [])
     _lib.profile_start(nprof)
-    for i in range(nprof):
-        engines[i % len(engines)].run(heads, streams[i % len(engines)])
+    run_plan(plan, engines, [], j)
     front_ms, nms_ms, gather_ms, calls = _lib.profile_stop()
     torch.cuda.synchronize()
-    # (b) one batch at a time on one stream, after 50 untimed calls to settle into that regime
-    for i in range(50):
-        engines[0].run(heads)
+    # (b) one launch at a time on one stream, still cycling through HBM
+    alone = {}
+    for i in range(16):
+        engines[0].run([input_sets[(i * S + t) % R] for t in range(S)])
     torch.cuda.synchronize()
     _lib.profile_start(nprof)
     for i in range(nprof):
-        engines[0].run(heads)
-    front_alone_ms, nms_alone_ms, gather_alone_ms, _ = _lib.profile_stop()
+        engines[0].run([input_sets[(i * S + t) % R] for t in range(S)])
+    alone["front"], alone["segment_nms"], alone["gather"], _ = _lib.profile_stop()
+    torch.cuda.synchronize()
+    # (c) the same S input sets every launch: they stay in the Infinity Cache
+    for i in range(8):
+        engines[0].run(input_sets[:S])
+    _lib.profile_start(nprof)
+    for i in range(nprof):
+        engines[0].run(input_sets[:S])
+    front_cached_ms, _, _, _ = _lib.profile_stop()
     torch.cuda.synchronize()
 
-    # the front kernel alone, as a train of launches between two events on one stream: its
-    # launch-to-launch period (kernel execution + the dispatch gap between dependent launches)
-    eng0 = engines[0]
-    eng0.params.reserved = 1
-    ntrain = 50
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(5):
-        eng0.run(heads)
-    ev0.record()
-    for _ in range(ntrain):
-        eng0.run(heads)
-    ev1.record()
-    torch.cuda.synchronize()
-    front_train_ms = ev0.elapsed_time(ev1) / ntrain
-    eng0.params.reserved = 0
-    eng0.run(heads)
-    torch.cuda.synchronize()
-
-    surv, kept, pairs = engines[0].segment_stats()
+    surv, kept, pairs, ties = engines[0].segment_stats()
+    surv, kept, pairs, ties = surv[0], kept[0], pairs[0], ties[0]       # set 0 = one batch
     total_surv, total_kept = int(surv.sum()), int(kept.sum())
+    pairs_launch = float(engines[0].stats[:, 2].to(torch.int64).sum().item())
 
     if rank == 0:
         n_anchors = batch * rows_per_image
         tiles = batch * sum(-(-(gh * gw) // 128) for gh, gw in engines[0].grids)
-        # algorithmic bytes of the front kernel: every anchor's 10 f32 logits read once,
-        # 28 B written per survivor (box 16, objectness 4, class score 4, class id 4) and one
-        # int32 survivor count per 128-cell tile
-        alg_bytes = 40.0 * n_anchors + 28.0 * total_surv + 4.0 * tiles
+        # algorithmic bytes of the front kernel per batch: every anchor's 10 f32 logits read
+        # once, 28 B written per survivor (box 16, objectness 4, class score 4, class id 4) and
+        # one int32 survivor count per 128-cell tile; a launch processes S batches
+        alg_batch = 40.0 * n_anchors + 28.0 * total_surv + 4.0 * tiles
+        alg_bytes = S * alg_batch
         achieved = alg_bytes / (front_ms * 1e-3) / 1e9
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_front_kernel_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r02_front_kernel_traffic.json")
         if os.path.exists(tfile) and not args.clustered:
             # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this
             # same command, collected offline and committed; see the file for the correction
-            traffic = json.load(open(tfile)).get(args.config, {}).get("traffic_bytes")
+            t = json.load(open(tfile)).get(args.config, {})
+            if t.get("sets_per_launch") == S:
+                traffic = t.get("traffic_bytes")
+        frac = lambda ms: round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         out = {
             "metric": "decode+NMS images/sec",
-            "value": round(world * batch * args.steps / elapsed, 1),
+            "value": round(world * batch * K / med, 1),
             "unit": "images/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(med / K * 1e3, 5),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (seeded N(0,1) offsets, N(0,0.5^2) sizes, N(-3,2^2) objectness "
-                    "logits%s; inputs resident in HBM)" % (", clustered" if args.clustered else ""),
+                    "logits%s; inputs resident in HBM, %d distinct copies = %d MiB cycled so that "
+                    "every batch is read from HBM, not from the 256 MiB Infinity Cache)"
+                    % (", clustered" if args.clustered else "", R, (R * batch_bytes) >> 20),
+            "timing": {"repeats": repeats, "statistic": "median over the repeats of the K-step timed "
+                       "region (each: barrier if N > 1, device sync, K steps, device sync, max over ranks)",
+                       "ms_per_step_min": round(min(times) / K * 1e3, 5),
+                       "ms_per_step_max": round(max(times) / K * 1e3, 5),
+                       "value_best_repeat": round(world * batch * K / min(times), 1)},
             "config": {"workload": "%s: %s; YOLOv3 heads stride 32/16/8 x 3 anchors, %d classes, "
                                    "NCHW f32" % (args.config, desc, NUM_CLASSES),
                        "batch_per_gpu": batch, "global_batch": batch * world,
@@ -425,57 +430,56 @@ def main():
                                       % world if world > 1 else "dp1",
                        "survivors_per_image": round(total_surv / batch, 1),
                        "kept_per_image": round(total_kept / batch, 1),
-                       "batches_in_flight": n_eng,
-                       "hw_queues_requested": int(os.environ["GPU_MAX_HW_QUEUES"]),
-                       "host_enqueue_us_per_step": round(t_enqueued / args.steps * 1e6, 2)},
-            "roofline": {"bound": "hbm", "kernel": "k_front_heads_v3 (decode+filter+compaction)",
+                       "iou_threshold_ties_per_batch": int(ties.sum()),
+                       "batches_per_launch": S, "launches_in_flight": F,
+                       "launches_per_timed_region": len(launch_plan(K)),
+                       "input_sets_cycled": R, "bytes_per_batch": batch_bytes,
+                       "host_enqueue_us_per_step": round(t_enq / K * 1e6, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_front_heads_v3_wave (decode+filter+compaction)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes": int(alg_bytes),
+                         "algorithmic_bytes_per_batch": int(alg_batch),
+                         "batches_per_launch": S,
                          "kernel_ms": round(front_ms, 5),
                          "kernel_ms_method": "mean over %d launches of the start/stop HIP events "
-                                             "attached to each launch on its stream, %d batches in "
-                                             "flight as in the timed region" % (calls, n_eng),
-                         "kernel_ms_alone": round(front_alone_ms, 5),
-                         "frac_alone": round(alg_bytes / (front_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "launch_train_period_ms": round(front_train_ms, 5),
-                         "whole_path_frac": round(alg_bytes / (elapsed / args.steps) / 1e9
-                                                  / HBM_PEAK_GBPS, 4)},
-            "kernels_ms": {"front": round(front_ms, 5), "segment_nms": round(nms_ms, 5),
+                                             "attached to each launch on its stream, %d launches in "
+                                             "flight and inputs cycling through HBM as in the timed "
+                                             "region" % (calls, F),
+                         "kernel_ms_alone": round(alone["front"], 5), "frac_alone": frac(alone["front"]),
+                         "kernel_ms_cache_resident": round(front_cached_ms, 5),
+                         "frac_cache_resident": frac(front_cached_ms),
+                         "whole_path_frac": round(alg_batch / (med / K) / 1e9 / HBM_PEAK_GBPS, 4)},
+            "kernels_ms": {"per": "launch of %d batches" % S,
+                           "front": round(front_ms, 5), "segment_nms": round(nms_ms, 5),
                            "gather": round(gather_ms, 5), "calls": calls,
-                           "alone": {"front": round(front_alone_ms, 5), "segment_nms": round(nms_alone_ms, 5),
-                                     "gather": round(gather_alone_ms, 5)},
-                           "nms_iou_pairs": int(pairs.astype(np.int64).sum()),
-                           "nms_iou_pairs_per_s": round(float(pairs.astype(np.int64).sum())
-                                                        / (nms_ms * 1e-3), 1)},
+                           "alone": {k: round(v, 5) for k, v in alone.items()},
+                           "nms_iou_pairs": int(pairs_launch),
+                           "nms_iou_pairs_per_s": round(pairs_launch / (nms_ms * 1e-3), 1)},
         }
         # NMS against the vector units' peak: one IoU test is ~22 VALU instructions per pair
         # (4 min/max, 2 sub+add, 2 clamps, product, union, 2 band products, 3-4 compares and
         # selects), the chip issues 256 CUs x 64 lanes per cycle at 2.4 GHz
         ops_per_pair, lane_ops_peak = 22.0, 256 * 64 * 2.4e9
-        pairs_per_s = float(pairs.astype(np.int64).sum()) / (nms_ms * 1e-3)
+        pairs_per_s = pairs_launch / (nms_ms * 1e-3)
+        all_pairs = S * float((surv.astype(np.float64) * (surv.astype(np.float64) - 1) / 2).sum())
         out["nms_roofline"] = {"bound": "valu", "achieved": round(pairs_per_s / 1e9, 2),
                                "peak": round(lane_ops_peak / ops_per_pair / 1e9, 1), "unit": "G IoU pairs/s",
                                "frac": round(pairs_per_s * ops_per_pair / lane_ops_peak, 4),
                                "ops_per_pair": ops_per_pair,
-                               "note": "pairs the kernel evaluated / its HIP-event time; the kernel also "
-                                       "gathers, sorts and sweeps, so this is a lower bound on the tile rate"}
+                               "algorithmic_pairs": int(all_pairs),
+                               "algorithmic_pairs_per_s": round(all_pairs / (nms_ms * 1e-3), 1),
+                               "note": "achieved = pairs the kernels evaluated / their HIP-event time "
+                                       "(the kernels also gather, sort and sweep); algorithmic pairs = "
+                                       "sum over segments of K(K-1)/2, what an unpruned greedy NMS tests"}
+        if times_nx is not None:
+            mnx = statistics.median(times_nx)
+            out["value_no_exchange"] = round(world * batch * K / mnx, 1)
+            out["ms_per_step_no_exchange"] = round(mnx / K * 1e3, 5)
         if multi:
-            out["config"]["exchange"] = (
-                "final: detections stay sharded by image during the steps; one variable-length RCCL "
-                "all-gather of the last batch's detection rows closes the timed region"
-                if args.exchange == "final" else
-                "every-step: one fixed-capacity RCCL all-gather of all ranks' detection rows per step, "
-                "overlapped with the following steps")
             out["config"].update(xinfo)
-            if other is not None:
-                out["config"]["other_exchange_mode"] = other
-        if world == 1 and args.config == "cfg2" and not args.clustered and not args.no_large_input:
-            # the same kernel on the path's largest single-GPU shape, where the launch is long
-            # enough for the fixed dispatch / drain cost of a 9 us kernel not to dominate
-            del engines
-            out["roofline_large_input"] = front_kernel_roofline("cfg3", dev)
         if not args.no_cpu_baseline and world == 1:
+            del engines
             out["cpu_baseline"] = cpu_baseline(cpu_heads, inp_dim, conf, nms, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)
     if multi:

@@ -44,6 +44,7 @@ extern "C" {
 
 #define YP_MAX_HEADS 4
 #define YP_MAX_ANCHORS 8
+#define YP_MAX_SETS 8 /* independent batches one yp_detect_yolov3_multi call can take */
 
 enum { YP_MODE_YOLOV3 = 0, YP_MODE_REFERENCE = 1 };
 
@@ -78,15 +79,15 @@ typedef struct YpParams {
     int32_t mode;         /* YP_MODE_* */
     int32_t batch;        /* B */
     int32_t num_classes;  /* C */
-    int32_t max_out;      /* per-image cap (params.max_boxes); <= 0 means unlimited */
+    int32_t max_out;      /* per-image cap (params.max_boxes).  YP_MODE_YOLOV3: <= 0 means
+                             unlimited.  YP_MODE_REFERENCE entries pad their outputs to max_out
+                             rows per image and require 1 <= max_out <= 2^20. */
     float conf_thr;       /* params.object_conf / `confidence` */
     float nms_thr;        /* params.nms_conf / `nms_conf` */
     float im_h;           /* YP_MODE_REFERENCE: params.im_height */
     float im_w;           /* YP_MODE_REFERENCE: params.im_width */
     int32_t batch_offset; /* YP_MODE_YOLOV3: added to the image index written in column 0 */
-    int32_t reserved;     /* 0 = run every stage.  Benchmarks of yp_detect_yolov3 may set a
-                             stage mask (1 front, 2 segment NMS, 4 gather) to time one kernel
-                             in isolation; later stages then reuse the workspace as it is. */
+    int32_t reserved;     /* must be 0 (anything else is YP_ERR_ARG) */
 } YpParams;
 
 int yp_version(void);
@@ -119,12 +120,33 @@ size_t yp_detect_yolov3_workspace_bytes(const YpHead *heads, int n_heads, int ba
  *   d_out_rows  (out_cap, 8) [image, x1, y1, x2, y2, objectness, class score, class id],
  *               ordered by image, class id ascending, objectness descending
  *   d_out_count [1] total detections D (rows beyond out_cap are not stored)
- *   d_stats     optional [3*B*C] int32: survivors, kept, IoU pairs evaluated (low 32 bits)
- *               per (image, class) segment; may be NULL */
+ *   d_stats     optional [4*B*C] int32, four planes of B*C per (image, class) segment:
+ *               survivors of the filter, kept rows, IoU pairs evaluated (low 32 bits), and
+ *               how many of those pairs had an IoU within 2^-20 (relative) of nms_thr -- the
+ *               IoU-at-threshold ties, decided by the exact divide-and-compare; may be NULL */
 int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params,
                      float *d_out_rows, int64_t out_cap, int32_t *d_out_count,
                      int32_t *d_stats, void *d_workspace, size_t workspace_bytes,
                      void *stream);
+
+/* Several independent batches ("sets") of identical geometry in ONE launch per stage.  The
+ * reference calls the path once per batch (run_validation, train.py:345-348); a caller that
+ * has n_sets batches ready (1..YP_MAX_SETS) hands them over together, which fills the GPU
+ * with n_sets times the workgroups per launch and costs one third of the host calls.
+ *   heads       n_sets * n_heads descriptors, set-major; every set repeats the geometry and
+ *               anchors of set 0, only `data` differs
+ *   params      shared by all sets; params->batch = images per set
+ *   d_out_rows  (n_sets, out_cap, 8): set s writes its rows from d_out_rows + s*out_cap*8
+ *               (out_cap even when n_sets > 1), image index in column 0 counts from
+ *               params->batch_offset inside every set
+ *   d_out_count [n_sets]
+ *   d_stats     optional (n_sets, 4, B, C), planes as in yp_detect_yolov3
+ *   workspace   yp_detect_yolov3_workspace_bytes(heads, n_heads, n_sets * batch, C)
+ * Results are identical to n_sets calls of yp_detect_yolov3. */
+int yp_detect_yolov3_multi(const YpHead *heads, int n_heads, int n_sets, const YpParams *params,
+                           float *d_out_rows, int64_t out_cap, int32_t *d_out_count,
+                           int32_t *d_stats, void *d_workspace, size_t workspace_bytes,
+                           void *stream);
 
 size_t yp_detect_reference_workspace_bytes(int batch, int grid_h, int grid_w, int num_anchors);
 

@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert declared == set(pkg._lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.yp_version() >= 100
+    assert lib.yp_version() >= 200
     assert lib.yp_strerror(0) == b"ok"
     assert b"workspace" in lib.yp_strerror(-2)
 
@@ -66,6 +66,52 @@ def test_bad_arguments_are_rejected_without_a_gpu(pkg):
     assert lib.yp_bbox_iou(None, fake, 3, 4, fake, None) == -1
     assert lib.yp_bbox_iou(fake, fake, 3, 2, fake, None) == -1
     assert lib.yp_write_results(None, 10, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
+    # the reserved field must be zero (it is no stage mask in the shipping library)
+    p.batch, p.reserved = 1, 2
+    assert lib.yp_detect_yolov3(heads, 1, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
+    assert lib.yp_write_results(fake, 10, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
+    p.reserved = 0
+    # reference-mode entries pad their outputs to max_out rows per image: 1 <= max_out <= 2^20
+    r = L.YpParams()
+    r.mode, r.batch, r.num_classes, r.conf_thr, r.nms_thr = L.YP_MODE_REFERENCE, 1, 5, 0.6, 0.5
+    r.im_h, r.im_w = 1280.0, 1920.0
+    rhead = L.make_head(None, 13, 13, [(1, 1)] * 5)
+    rhead.data = 0x1000
+    for bad in (0, -1, (1 << 20) + 1):
+        r.max_out = bad
+        assert lib.yp_detect_reference(ctypes.byref(rhead), ctypes.byref(r), fake, fake, fake, fake, fake,
+                                       fake, fake, 1 << 30, None) == -1
+        assert lib.yp_filter_boxes_reference(fake, fake, fake, fake, 845, ctypes.byref(r), fake, fake,
+                                             fake, fake, fake, fake, fake, 1 << 30, None) == -1
+
+
+def test_multi_set_arguments_are_validated_without_a_gpu(pkg):
+    L, lib = pkg._lib, pkg._lib.load()
+    p = L.YpParams()
+    p.mode, p.batch, p.num_classes, p.conf_thr, p.nms_thr = L.YP_MODE_YOLOV3, 2, 5, 0.5, 0.4
+    fake = ctypes.c_void_p(0x1000)
+
+    def sets(n, grid=13):
+        hs = [L.make_head(None, 13, 13, [(1, 1)] * 3, 32, 32) for _ in range(n)]
+        for h in hs:
+            h.data = 0x1000
+        hs[-1].grid_h = grid
+        return (L.YpHead * n)(*hs)
+
+    call = lambda heads, n, cap=10: lib.yp_detect_yolov3_multi(
+        heads, 1, n, ctypes.byref(p), fake, cap, fake, None, fake, 1 << 30, None)
+    assert call(sets(2), 0) == -3 and call(sets(2), L.YP_MAX_SETS + 1) == -3
+    assert call(sets(2), 2, cap=11) == -1          # odd capacity would misalign set 1's rows
+    assert call(sets(2, grid=14), 2) == -1         # a set whose geometry differs from set 0
+    hs = sets(2)
+    hs[1].data = 0
+    assert call(hs, 2) == -1                       # null data pointer in a later set
+    # a workspace sized for one set is too small for two
+    one = lib.yp_detect_yolov3_workspace_bytes(sets(1), 1, 2, 5)
+    two = lib.yp_detect_yolov3_workspace_bytes(sets(1), 1, 4, 5)
+    assert two > one
+    assert lib.yp_detect_yolov3_multi(sets(2), 1, 2, ctypes.byref(p), fake, 10, fake, None, fake, one,
+                                      None) == -2
 
 
 def test_product_refuses_to_run_without_a_device(pkg):

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_has_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5",
-                          "--cpu-baseline-seconds", "1", "--no-large-input"],
+                          "--cpu-baseline-seconds", "2", "--repeats", "5"],
                          cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -37,4 +37,8 @@ def test_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["value_1core"] > 0
+    t = d["timing"]
+    assert t["repeats"] == 5 and t["ms_per_step_min"] <= d["ms_per_step"] <= t["ms_per_step_max"]
+    assert d["config"]["input_sets_cycled"] * d["config"]["bytes_per_batch"] >= 512 << 20
+    assert r["batches_per_launch"] == d["config"]["batches_per_launch"]

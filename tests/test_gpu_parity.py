@@ -530,6 +530,80 @@ def test_gpu_matches_committed_golden_vectors(pkg, dev):
         assert np.array_equal(util.write_results(rows, 0.5, 3, thr).cpu().numpy(), g["det_" + name])
 
 
+# ------------------------------------------------------------------ several sets per launch
+
+@pytest.mark.parametrize("n_sets,B,inp_dim,conf,clustered", [
+    (4, 8, 416, 0.5, False), (3, 2, (320, 480), 0.3, True), (8, 1, 416, 0.5, True),
+    (2, 2, 416, 0.001, False),     # segments beyond the all-pairs path in every set
+])
+def test_v3_multi_set_launch_equals_single_set_calls(pkg, dev, n_sets, B, inp_dim, conf, clustered):
+    """yp_detect_yolov3_multi: n_sets independent batches in one launch per stage give, set by
+    set, the rows, counts and statistics of yp_detect_yolov3 on that batch (and the oracle's)."""
+    syn, util = pkg.synthetic, pkg.util
+    sets = [[h.to(dev) for h in syn.make_heads(B, inp_dim, 5, seed=4000 + 17 * k, clustered=clustered)]
+            for k in range(n_sets)]
+    multi = util.YoloV3PostMulti(n_sets, B, inp_dim, 5, conf, 0.4, device=dev, batch_offset=3)
+    one = util.YoloV3Post(B, inp_dim, 5, conf, 0.4, device=dev, batch_offset=3)
+    got = [d.cpu().numpy() for d in multi.detect(sets)]
+    m_stats = multi.segment_stats()
+    for k in range(n_sets):
+        want = one.detect(sets[k]).cpu().numpy()
+        assert got[k].shape == want.shape, k
+        assert np.array_equal(got[k], want), k
+        refs = one.segment_stats() + (one.tie_stats(),)
+        # survivors and kept rows always; evaluated pairs and ties only where every segment takes
+        # the all-pairs path (above it, which pairs get pruned depends on the order LDS atomics
+        # hand out list positions, so the count varies from run to run while the result does not)
+        planes = 4 if refs[0].max() <= 512 else 2
+        for plane, ref in list(zip(m_stats, refs))[:planes]:
+            assert np.array_equal(plane[k], ref), k
+    w0, _, _ = v3_oracle([h.cpu() for h in sets[0]], inp_dim, syn.YOLOV3_ANCHORS, 5, conf, 0.4)
+    w0[:, 0] += 3
+    assert np.array_equal(got[0], w0)
+    # fewer sets than the engine was built for, and a second run on the same buffers
+    part = [d.cpu().numpy() for d in multi.detect(sets[:max(1, n_sets - 1)])]
+    for k in range(len(part)):
+        assert np.array_equal(part[k], got[k])
+
+
+def test_v3_engine_revalidates_views_of_cached_buffers(pkg, dev):
+    """The descriptor cache is keyed on address, shape, strides and dtype: a partial batch that
+    aliases a cached input buffer is rejected instead of being processed with stale images."""
+    syn, util = pkg.synthetic, pkg.util
+    heads = [h.to(dev) for h in syn.make_heads(4, 416, 5, seed=31)]
+    eng = util.YoloV3Post(4, 416, 5, 0.5, 0.4, device=dev)
+    eng.run(heads)
+    with pytest.raises(ValueError):
+        eng.run([h[:2] for h in heads])
+    with pytest.raises(ValueError):
+        eng.run([heads[0], heads[1], heads[2][:, :, ::2]])
+    with pytest.raises(ValueError):
+        util.predict_transform_heads([heads[0], heads[1][:2], heads[2]], 416, syn.YOLOV3_ANCHORS, 5)
+
+
+def test_v3_threshold_ties_are_counted(pkg, dev):
+    """Pairs whose IoU sits at the threshold (within 2^-20 relative) are reported per segment:
+    unit-spaced boxes with IoU(+1) exactly 1/3 and 1/2, run at those thresholds and beside them."""
+    util = pkg.util
+    C = 2
+
+    def row(cx, cy, w, h, obj):
+        return [cx, cy, w, h, obj, 0.9, 0.1]
+    # boxes [0,0,1,0]..: widths chosen so that the +1 areas are 2x1 and the overlap 1x1 -> 1/3
+    rows = np.array([[row(0.5, 0.0, 1, 0, 0.9), row(1.5, 0.0, 1, 0, 0.8),     # IoU(+1) = 1/3
+                      row(50.5, 50.0, 1, 0, 0.9), row(50.5, 50.5, 1, 1, 0.8),  # 2 vs 4, overlap 2 -> 1/2
+                      row(90.0, 90.0, 3, 3, 0.7)]], np.float32)
+    d_rows = torch.from_numpy(rows).to(dev)
+    for thr, want_ties in ((1.0 / 3.0, 1), (0.5, 1), (0.4, 0), (0.33, 0)):
+        out, count, stats = util.write_results_device(d_rows, 0.5, C, thr, want_stats=True)
+        want, _, _ = oracle.n_write_results(rows, 0.5, C, thr)
+        assert np.array_equal(out[:int(count.item())].cpu().numpy(), want), thr
+        st = stats.cpu().numpy()
+        assert st.shape == (4, 1, C)
+        assert int(st[3].sum()) == want_ties, (thr, st[3])
+        assert int(st[2, 0, 0]) == 10                                        # 5 rows -> 10 pairs
+
+
 # ------------------------------------------------------------------ batches in flight
 
 def test_v3_batches_in_flight_on_separate_streams_do_not_interfere(pkg, dev):

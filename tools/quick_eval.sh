@@ -6,8 +6,8 @@ mkdir -p gpurun_out
 timeout -k 10 400 python -u -m pytest tests/test_gpu_parity.py -x -q --timeout 120 --timeout-method thread > gpurun_out/quick_parity.log 2>&1
 tail -1 gpurun_out/quick_parity.log
 : > gpurun_out/quick_eval.txt
-for args in "--config cfg2" "--config cfg2" "--config cfg2 --in-flight 1" "--config cfg3 --steps 60" "--config cfg4"; do
-  timeout -k 10 120 python bench.py --no-cpu-baseline --no-large-input $args > gpurun_out/quick_one.json
+for args in "--config cfg2" "--config cfg2" "--config cfg2 --in-flight 1 --sets-per-launch 1" "--config cfg3 --steps 60" "--config cfg4"; do
+  timeout -k 10 120 python bench.py --no-cpu-baseline $args > gpurun_out/quick_one.json
   python3 - "$args" <<'PY' >> gpurun_out/quick_eval.txt
 import json, sys
 d = json.loads(open("gpurun_out/quick_one.json").read().strip().splitlines()[-1])
