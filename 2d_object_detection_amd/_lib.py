@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = (
     "yp_version", "yp_strerror",
     "yp_predict_transform_reference", "yp_predict_transform_yolov3",
     "yp_detect_yolov3_workspace_bytes", "yp_detect_yolov3", "yp_detect_yolov3_multi",
+    "yp_noalloc_scratch_bytes", "yp_noalloc_prepare", "yp_detect_yolov3_noalloc",
     "yp_detect_reference_workspace_bytes", "yp_detect_reference",
     "yp_rows_workspace_bytes", "yp_write_results", "yp_filter_boxes_reference",
     "yp_bbox_iou", "yp_profile_start", "yp_profile_stop",
@@ -98,6 +99,13 @@ def load():
     L.yp_detect_yolov3_multi.restype = i32
     L.yp_detect_yolov3_multi.argtypes = [ctypes.POINTER(YpHead), i32, i32, ctypes.POINTER(YpParams),
                                          vp, i64, vp, vp, vp, sz, vp]
+    L.yp_noalloc_scratch_bytes.restype = sz
+    L.yp_noalloc_scratch_bytes.argtypes = []
+    L.yp_noalloc_prepare.restype = i32
+    L.yp_noalloc_prepare.argtypes = []
+    L.yp_detect_yolov3_noalloc.restype = i32
+    L.yp_detect_yolov3_noalloc.argtypes = [ctypes.POINTER(YpHead), i32, ctypes.POINTER(YpParams), vp,
+                                           i64, vp, vp, vp]
     L.yp_detect_reference_workspace_bytes.restype = sz
     L.yp_detect_reference_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.yp_detect_reference.restype = i32

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <mutex>
+
 #include "yolopost.h"
 #include "yp_math.h"
 #include "yp_tile.h"
@@ -2239,6 +2241,9 @@ const char *yp_strerror(int code)
     case YP_ERR_ARG: return "invalid argument";
     case YP_ERR_WORKSPACE: return "workspace missing, misaligned or too small";
     case YP_ERR_UNSUPPORTED: return "shape beyond the compiled limits";
+    case YP_ERR_SCRATCH:
+        return "problem needs more scratch than the library's static buffer "
+               "(yp_noalloc_scratch_bytes); use yp_detect_yolov3 with a caller workspace";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
@@ -2379,6 +2384,67 @@ int yp_detect_yolov3_multi(const YpHead *heads, int n_heads, int n_sets, const Y
 {
     return detect_v3_sets(heads, n_heads, n_sets, params, d_out_rows, out_cap, d_out_count,
                           d_stats, d_workspace, workspace_bytes, stream);
+}
+
+// ---- the entry point that allocates nothing -------------------------------------------
+// Scratch of yp_detect_yolov3_noalloc: the workspace yp_detect_yolov3 takes from its caller,
+// held by the library instead.  Every GPU the library runs on has its own copy of this array
+// at its own address; host code never uses the array's name as an address, only the pointer
+// hipGetSymbolAddress returns for the device that was current when it was asked.
+static __device__ __align__(256) unsigned char scratch[YP_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+void *g_scratch_ptr[kMaxDevices];        // per device, filled once by noalloc_scratch()
+std::mutex g_scratch_mutex;
+
+// Device address of `scratch` on the current device (looked up once per device).
+int noalloc_scratch(void **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= kMaxDevices) return YP_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!ptr || (reinterpret_cast<uintptr_t>(ptr) % kAlign) != 0) return YP_ERR_WORKSPACE;
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return YP_OK;
+}
+}  // namespace
+
+size_t yp_noalloc_scratch_bytes(void) { return (size_t)YP_NOALLOC_SCRATCH_BYTES; }
+
+int yp_noalloc_prepare(void)
+{
+    void *ptr = nullptr;
+    return noalloc_scratch(&ptr);
+}
+
+int yp_detect_yolov3_noalloc(const YpHead *heads, int n_heads, const YpParams *params,
+                             float *d_out_rows, int64_t out_cap, int32_t *d_out_count,
+                             int32_t *d_stats, void *stream)
+{
+    if (!params || params->batch <= 0 || params->num_classes <= 0) return YP_ERR_ARG;
+    // the size test comes first: a problem beyond the static buffer is refused before anything
+    // is launched (0 = the geometry itself is invalid or beyond the compiled limits)
+    const size_t need = yp_detect_yolov3_workspace_bytes(heads, n_heads, params->batch,
+                                                         params->num_classes);
+    if (need == 0) return YP_ERR_ARG;
+    if (need > (size_t)YP_NOALLOC_SCRATCH_BYTES) return YP_ERR_SCRATCH;
+    void *ptr = nullptr;
+    const int rc = noalloc_scratch(&ptr);
+    if (rc != YP_OK) return rc;
+    // every array of the workspace is written by the kernels before it is read (tile counts by
+    // the front kernel, segment records and flags by the NMS kernel), so nothing has to be
+    // cleared between calls; what an earlier, larger call left behind is never looked at
+    return detect_v3_sets(heads, n_heads, 1, params, d_out_rows, out_cap, d_out_count, d_stats, ptr,
+                          (size_t)YP_NOALLOC_SCRATCH_BYTES, stream);
 }
 
 size_t yp_rows_workspace_bytes(int batch, int rows_per_image, int segments_per_image)

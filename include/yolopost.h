@@ -52,7 +52,8 @@ enum {
     YP_OK = 0,
     YP_ERR_ARG = -1,        /* null pointer, non-positive size, value out of range */
     YP_ERR_WORKSPACE = -2,  /* workspace missing, misaligned or too small */
-    YP_ERR_UNSUPPORTED = -3 /* shape beyond the compiled limits (heads, anchors, sizes) */
+    YP_ERR_UNSUPPORTED = -3, /* shape beyond the compiled limits (heads, anchors, sizes) */
+    YP_ERR_SCRATCH = -4      /* yp_detect_yolov3_noalloc: needs more than the static scratch */
 };
 
 /* One detection head.
@@ -147,6 +148,25 @@ int yp_detect_yolov3_multi(const YpHead *heads, int n_heads, int n_sets, const Y
                            float *d_out_rows, int64_t out_cap, int32_t *d_out_count,
                            int32_t *d_stats, void *d_workspace, size_t workspace_bytes,
                            void *stream);
+
+/* yp_detect_yolov3 for callers that cannot allocate device memory -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in
+ * the reference.  Same inputs, outputs and results as yp_detect_yolov3, but the workspace is a
+ * static device array inside the library (YP_NOALLOC_SCRATCH_BYTES = 16 MiB per GPU the
+ * library runs on, held until the process ends); the call allocates and frees nothing.
+ * Problems whose workspace (yp_detect_yolov3_workspace_bytes) exceeds that size return
+ * YP_ERR_SCRATCH and launch nothing: 16 MiB covers e.g. 16 images at 416x416 or one image at
+ * 1920x1280 with three anchors per head.  All calls on one GPU share that GPU's array: calls
+ * that overlap on one GPU (different streams or threads) race; order them on one stream.
+ * The array's device address is looked up on the first call on each device;
+ * yp_noalloc_prepare() does that lookup for the current device ahead of time (e.g. before a
+ * graph capture starts). */
+#define YP_NOALLOC_SCRATCH_BYTES (16u << 20)
+size_t yp_noalloc_scratch_bytes(void);
+int yp_noalloc_prepare(void);
+int yp_detect_yolov3_noalloc(const YpHead *heads, int n_heads, const YpParams *params,
+                             float *d_out_rows, int64_t out_cap, int32_t *d_out_count,
+                             int32_t *d_stats, void *stream);
 
 size_t yp_detect_reference_workspace_bytes(int batch, int grid_h, int grid_w, int num_anchors);
 
