@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Turn tools/pmc_summary.py output (FETCH_SIZE / WRITE_SIZE means per launch, KiB) of the front
+kernel into the per-launch HBM traffic record bench.py reports as roofline.traffic.
+Usage: python tools/traffic_json.py <pmc_summary.json> <config> <sets_per_launch> <out.json>"""
+import json
+import sys
+
+src, cfg, sets, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+s = json.load(open(src))
+name = [k for k in s if "k_front_heads_v3" in k][0]
+fetch, write = s[name]["FETCH_SIZE"]["mean"], s[name]["WRITE_SIZE"]["mean"]
+try:
+    out = json.load(open(dst))
+except (OSError, ValueError):
+    out = {}
+out[cfg] = {
+    "kernel": name.split("::")[-1].split("(")[0], "sets_per_launch": sets,
+    "launches_averaged": s[name]["FETCH_SIZE"]["launches"],
+    "FETCH_SIZE_KiB_raw": round(fetch, 1), "WRITE_SIZE_KiB": round(write, 1),
+    "fetch_bytes_corrected": int(2 * fetch * 1024), "write_bytes": int(write * 1024),
+    "traffic_bytes": int(2 * fetch * 1024 + write * 1024),
+    "note": "per launch; FETCH_SIZE doubled (gfx950 tallies the 128-B requests of a coalesced stream "
+            "at 64 B; calibrated in round 1 on a 387 MB input where 2*FETCH matched the input bytes to "
+            "0.03%); separate rocprofv3 --pmc passes of `python3 bench.py --no-cpu-baseline --steps 20 "
+            "--warmup 2` (tools/profile_round.sh)",
+}
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(out[cfg]))
