@@ -3,6 +3,7 @@
 kernel into the per-launch HBM traffic record bench.py reports as roofline.traffic.
 Usage: python tools/traffic_json.py <pmc_summary.json> <config> <sets_per_launch> <out.json>"""
 import json
+import re
 import sys
 
 src, cfg, sets, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
@@ -14,7 +15,7 @@ try:
 except (OSError, ValueError):
     out = {}
 out[cfg] = {
-    "kernel": name.split("::")[-1].split("(")[0], "sets_per_launch": sets,
+    "kernel": re.search(r"k_front_heads_v3\w*(<[^>]*>)?", name).group(0), "sets_per_launch": sets,
     "launches_averaged": s[name]["FETCH_SIZE"]["launches"],
     "FETCH_SIZE_KiB_raw": round(fetch, 1), "WRITE_SIZE_KiB": round(write, 1),
     "fetch_bytes_corrected": int(2 * fetch * 1024), "write_bytes": int(write * 1024),
