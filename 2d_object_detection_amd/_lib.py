@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = (
     "yp_noalloc_scratch_bytes", "yp_noalloc_prepare", "yp_detect_yolov3_noalloc",
     "yp_detect_reference_workspace_bytes", "yp_detect_reference",
     "yp_rows_workspace_bytes", "yp_write_results", "yp_filter_boxes_reference",
-    "yp_bbox_iou", "yp_profile_start", "yp_profile_stop",
+    "yp_bbox_iou", "yp_profile_start", "yp_profile_stop", "yp_profile_stop_ex",
     "yp_encode_true_box_grid", "yp_true_box_grid_workspace_bytes", "yp_decode_true_box_grid",
     "yp_predict_transform_reference_backward",
     "yp_loss_custom_reference_workspace_bytes", "yp_loss_custom_reference",
@@ -125,6 +125,8 @@ def load():
     dp = ctypes.POINTER(ctypes.c_double)
     L.yp_profile_stop.restype = i32
     L.yp_profile_stop.argtypes = [dp, dp, dp, ctypes.POINTER(ctypes.c_int)]
+    L.yp_profile_stop_ex.restype = i32
+    L.yp_profile_stop_ex.argtypes = [dp, ctypes.POINTER(ctypes.c_int)]
     L.yp_encode_true_box_grid.restype = i32
     L.yp_encode_true_box_grid.argtypes = [vp, vp, i32, i32, i32, i32, fp, i32, i32, vp, vp, vp]
     L.yp_true_box_grid_workspace_bytes.restype = sz
@@ -218,6 +220,15 @@ def profile_stop():
     check(load().yp_profile_stop(ctypes.byref(f), ctypes.byref(n), ctypes.byref(g), ctypes.byref(c)),
           "yp_profile_stop")
     return f.value, n.value, g.value, c.value
+
+
+def profile_stop_ex():
+    """Average milliseconds per recorded call of (front, segment NMS, row gather, graph pair tests,
+    graph resolve) and the number of calls."""
+    ms = (ctypes.c_double * 5)()
+    c = ctypes.c_int()
+    check(load().yp_profile_stop_ex(ms, ctypes.byref(c)), "yp_profile_stop_ex")
+    return list(ms), c.value
 
 
 def make_head(t, grid_h, grid_w, anchors, stride_x=0.0, stride_y=0.0):

@@ -51,6 +51,10 @@ constexpr int kSmallWords = kSmallCap / 64;
 constexpr int kMaskWords = kSmallWords * kSmallCap - 32 * kSmallWords * (kSmallWords - 1);
 constexpr int kRawBytes = (kSortCap * 8 > kMaskWords * 8) ? kSortCap * 8 : kMaskWords * 8;
 constexpr int kSmallBytes = 32 * (kSmallCap + 8) + 16 * 32;   // + 32 boxes the pair loop may over-read
+#ifndef YP_GRAPH_MIN
+#define YP_GRAPH_MIN 768
+#endif
+struct GraphSeg;
 
 // ------------------------------------------------------------------------ device structs
 
@@ -90,7 +94,19 @@ struct CandBuf {
     int *tile_count;
     int tpi;  // tiles per image
     int ts;   // slots per tile
+    int *ctrl;  // launch control words, cleared by the front kernel: [0] some segment took the
+                // graph path, [1] bin tables handed out
 };
+
+// The first thread of a front kernel clears the control words of the launch (the kernels that
+// follow on the stream set and read them).
+__device__ __forceinline__ void clear_ctrl(const CandBuf &cb)
+{
+    if (cb.ctrl && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        cb.ctrl[0] = 0;
+        cb.ctrl[1] = 0;
+    }
+}
 
 struct SegArgs {
     int B, C, spi, tpi, ts, per_class, max_out, batch_offset;
@@ -114,6 +130,11 @@ struct SegArgs {
     unsigned int *seg_pairs; // [n_seg] IoU evaluations (low 32 bits)
     unsigned int *seg_ties;  // [n_seg] evaluated pairs whose IoU lay within 2^-20 (relative) of the
                              // threshold, i.e. that needed the exact divide-and-compare
+    GraphSeg *gseg;          // [n_seg] index descriptors of the graph path (null: path disabled)
+    int *bin_tables;         // pool of bin offset tables for it
+    int *glist;              // graph segments of the launch, indexed like the tables
+    int *gcnt, *gedge;       // suppressor records the graph kernels fill (cleared here)
+    int *ctrl;               // launch control words (see CandBuf)
     // reference-mode outputs, padded to max_out rows per image
     float *out_boxes;
     float *out_scores;
@@ -354,6 +375,7 @@ __global__ void k_front_heads_v3(HeadsArgs ha, CandBuf cb, float conf, float t_l
         store_cand(cb, ((size_t)b * cb.tpi + tile) * cb.ts + r, bx, obj + 0.0f, best, bi);
     }
     if (threadIdx.x == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = total;
+    clear_ctrl(cb);
 }
 
 // One-wave variant of the heads front kernel for a compile-time class count CS and anchor
@@ -572,6 +594,7 @@ void k_front_heads_v3_wave(HeadsArgs ha, CandBuf cb, float conf,
         __builtin_amdgcn_wave_barrier();   // the next round overwrites the staging area
     }
     if (lane == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = total;
+    clear_ctrl(cb);
 #ifdef YP_STAMPS
     if (lane == 0 && ha.dbg) ha.dbg[dbg_blk * 4 + 3] = wall_clock64();
 #endif
@@ -678,6 +701,7 @@ __global__ void k_front_grid_ref(const float *pred, int H, int W, int A, int C_a
         store_cand(cb, slot0 + rank, bx, best, 0.f, bi);
     }
     if (threadIdx.x == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = total;
+    clear_ctrl(cb);
 }
 
 // ------------------------------------------------------- front: decoded reference 4-tuple
@@ -714,6 +738,7 @@ __global__ void k_front_split_ref(const float *center, const float *wh, const fl
     const int rank = tile_rank_rows(pass, s_bal, total);
     if (pass) store_cand(cb, ((size_t)b * cb.tpi + tile) * cb.ts + rank, bx, best, 0.f, bi);
     if (threadIdx.x == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = total;
+    clear_ctrl(cb);
 }
 
 // ------------------------------------------------------------ front: decoded YOLOv3 rows
@@ -750,6 +775,7 @@ __global__ void k_front_rows_v3(const float *rows, int N, int C, CandBuf cb, flo
     const int rank = tile_rank_rows(pass, s_bal, total);
     if (pass) store_cand(cb, ((size_t)b * cb.tpi + tile) * cb.ts + rank, bx, ob + 0.0f, best, bi);
     if (threadIdx.x == 0) cb.tile_count[(size_t)b * cb.tpi + tile] = total;
+    clear_ctrl(cb);
 }
 
 // --------------------------------------------------------------------------------- sorting
@@ -1211,6 +1237,8 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
     return nkept;
 }
 
+#include "yp_graph.h"
+
 template <int MODE>
 #ifndef YP_PAIR_UNROLL
 #define YP_PAIR_UNROLL 3
@@ -1257,6 +1285,7 @@ void k_segment_nms(SegArgs s)
     if (tid < 4) s_cnt[tid] = 0;
     if (tid == 0) s_pairs = 0u;
     if (tid == 1) s_ties = 0u;
+    if (MODE == YP_MODE_YOLOV3 && tid == 0 && s.gseg) s.gseg[seg].K = 0;
     STAMP(0);
 
     // ---- exclusive prefix of the image's tile counts: a kept row's position in the image's
@@ -1662,6 +1691,167 @@ void k_segment_nms(SegArgs s)
         __syncthreads();
         STAMP(4);
         sslot_final = gslot;
+        // ---- graph path: a segment this large is not swept here.  It gets a spatial index (boxes
+        // binned by size class and by the cell of their centre, see yp_graph.h) and is finished
+        // by k_graph_pairs / k_graph_resolve, which spread it over many workgroups.
+        if (MODE == YP_MODE_YOLOV3 && s.gseg != nullptr && K > kGraphMin && K <= (1 << 20) &&
+            s.thr >= 0.05f && s.thr <= 1.0f) {
+            float *s_redf = reinterpret_cast<float *>(&s_chunk);   // [kSegWaves][8] partial results
+            GraphSeg *s_g = reinterpret_cast<GraphSeg *>(s_redf + 8 * kSegWaves);
+            static_assert(sizeof(ChunkShared) >= 8 * kSegWaves * 4 + sizeof(GraphSeg) + 16, "scratch fits");
+            int *s_hist = reinterpret_cast<int *>(s_lds), *s_cur = s_hist + kGraphBins;
+            static_assert(2 * kGraphBins * 4 <= kRawBytes + kSmallBytes, "histogram and cursors fit");
+            const float inf = __builtin_inff();
+            float xlo = inf, xhi = -inf, ylo = inf, yhi = -inf, mlo = inf, mhi = -inf;
+            bool ok = true;
+            for (int i = tid; i < K; i += kSegThreads) {
+                const float4 c4 = gbox[i];
+                const float w = c4.z - c4.x + 1.0f, h = c4.w - c4.y + 1.0f;
+                const float size = w > h ? w : h;
+                const float cx = 0.5f * (c4.x + c4.z), cy = 0.5f * (c4.y + c4.w);
+                // (comparisons that a NaN fails)
+                ok = ok && (w > 0.0f) && (h > 0.0f) && (size < 1e30f) && (__builtin_fabsf(cx) < 1e30f) &&
+                     (__builtin_fabsf(cy) < 1e30f);
+                xlo = vmin(xlo, cx); xhi = vmax(xhi, cx);
+                ylo = vmin(ylo, cy); yhi = vmax(yhi, cy);
+                mlo = vmin(mlo, size); mhi = vmax(mhi, size);
+            }
+            xlo = wave_min_f(xlo); xhi = wave_max_f(xhi);
+            ylo = wave_min_f(ylo); yhi = wave_max_f(yhi);
+            mlo = wave_min_f(mlo); mhi = wave_max_f(mhi);
+            const bool wave_ok = __ballot(ok) == ~0ull;
+            if (lane == 0) {
+                float *r = s_redf + 8 * wave;
+                r[0] = xlo; r[1] = xhi; r[2] = ylo; r[3] = yhi; r[4] = mlo; r[5] = mhi;
+                r[6] = wave_ok ? 1.0f : 0.0f;
+            }
+            if (tid < kGraphClasses) s_cur[tid] = 0;
+            __syncthreads();
+            bool all_ok = true;
+            xlo = inf; xhi = -inf; ylo = inf; yhi = -inf; mlo = inf; mhi = -inf;
+            for (int w = 0; w < kSegWaves; ++w) {
+                const float *r = s_redf + 8 * w;
+                xlo = vmin(xlo, r[0]); xhi = vmax(xhi, r[1]);
+                ylo = vmin(ylo, r[2]); yhi = vmax(yhi, r[3]);
+                mlo = vmin(mlo, r[4]); mhi = vmax(mhi, r[5]);
+                all_ok = all_ok && r[6] != 0.0f;
+            }
+            if (all_ok) {     // (uniform over the workgroup)
+                const int e_min = (int)((__float_as_uint(mlo) >> 23) & 255u);
+                for (int i = tid; i < K; i += kSegThreads)
+                    atomicAdd(&s_cur[graph_class(graph_box_size<MODE>(gbox[i]), e_min)], 1);
+                __syncthreads();
+                if (tid == 0) {
+                    GraphSeg g;
+                    g.K = K;
+                    g.table = atomicAdd(&s.ctrl[1], 1);
+                    g.e_min = e_min;
+                    int d = 0;
+                    while ((float)(1 << d) < 1.001f / s.thr) ++d;
+                    g.d = d;
+                    g.x0 = xlo;
+                    g.y0 = ylo;
+                    g.margin = 2.0f + 4e-7f * (__builtin_fabsf(xlo) + __builtin_fabsf(xhi) +
+                                               __builtin_fabsf(ylo) + __builtin_fabsf(yhi) + mhi);
+                    const float xr = xhi - xlo, yr = yhi - ylo;
+                    int base = 0;
+                    for (int c = 0; c < kGraphClasses; ++c) {
+                        const int n_c = s_cur[c];
+                        g.nx[c] = g.ny[c] = 0;
+                        g.base[c] = base;
+                        g.invx[c] = g.invy[c] = 0.0f;
+                        g.half[c] = 0.0f;
+                        if (n_c == 0) continue;
+                        // sizes of class c < last have biased exponent e_min + c, i.e. lie below
+                        // 2^(e_min + c + 1 - 127); the last class takes everything above its start
+                        float ub = __uint_as_float((unsigned)(e_min + c + 1 < 254 ? e_min + c + 1 : 254) << 23);
+                        if (c == kGraphClasses - 1) ub = vmax(ub, mhi * 1.0001f);
+                        g.half[c] = 0.5f * ub;
+                        // The class gets a share of the bins in proportion to its boxes.  64
+                        // consecutive index positions (one batch of columns) are a run of cells
+                        // along x, so the cells are made as tall as such a run is long -- about
+                        // sqrt(64 / density) -- and as narrow as the share allows: the batch then
+                        // covers a roughly square patch, which keeps its reach small.
+                        const int budget = 8 + (int)((long long)(kGraphBins - 8 * kGraphClasses) * n_c / K);
+                        int ny = 1;
+                        if (yr > 0.0f && xr > 0.0f) {
+                            const float h = __builtin_sqrtf(64.0f * xr * (yr / (float)n_c));
+                            const float fy = h > 0.0f ? yr / h : 1.0f;
+                            ny = fy < 1.0f ? 1 : (fy > (float)budget ? budget : (int)fy);
+                        } else if (yr > 0.0f) {
+                            ny = budget;
+                        }
+                        int nx = xr > 0.0f ? budget / ny : 1;
+                        nx = nx < 1 ? 1 : nx;
+                        g.nx[c] = nx;
+                        g.ny[c] = ny;
+                        g.invx[c] = xr > 0.0f ? (float)nx / xr : 0.0f;
+                        g.invy[c] = yr > 0.0f ? (float)ny / yr : 0.0f;
+                        if (!(g.invx[c] < 3e38f)) g.invx[c] = 0.0f, g.nx[c] = 1;   // (degenerate range)
+                        if (!(g.invy[c] < 3e38f)) g.invy[c] = 0.0f, g.ny[c] = 1;
+                        base += g.nx[c] * g.ny[c];
+                    }
+                    g.n_bins = base;
+                    *s_g = g;
+                }
+                __syncthreads();
+                const GraphSeg &g = *s_g;
+                for (int i = tid; i < kGraphBins; i += kSegThreads) s_hist[i] = 0;
+                __syncthreads();
+                auto bin_of = [&](const float4 &c4) {
+                    const int c = graph_class(graph_box_size<MODE>(c4), g.e_min);
+                    const int ix = graph_cell(0.5f * (c4.x + c4.z), g.x0, g.invx[c], g.nx[c]);
+                    const int iy = graph_cell(0.5f * (c4.y + c4.w), g.y0, g.invy[c], g.ny[c]);
+                    return g.base[c] + iy * g.nx[c] + ((iy & 1) ? g.nx[c] - 1 - ix : ix);
+                };
+                for (int i = tid; i < K; i += kSegThreads) atomicAdd(&s_hist[bin_of(gbox[i])], 1);
+                __syncthreads();
+                {   // exclusive scan of the kGraphBins counts: 8 consecutive bins per thread
+                    constexpr int kPer = kGraphBins / kSegThreads;
+                    int loc[kPer], sum = 0;
+#pragma unroll
+                    for (int k = 0; k < kPer; ++k) {
+                        loc[k] = sum;
+                        sum += s_hist[tid * kPer + k];
+                    }
+                    const int incl = wave_inclusive_scan(sum, lane);
+                    if (lane == 63) s_scan[wave] = incl;
+                    __syncthreads();
+                    int woff = 0;
+                    for (int w = 0; w < kSegWaves; ++w) woff += w < wave ? s_scan[w] : 0;
+                    int *table = s.bin_tables + (size_t)g.table * (kGraphBins + 1);
+#pragma unroll
+                    for (int k = 0; k < kPer; ++k) {
+                        const int o = woff + incl - sum + loc[k];
+                        s_cur[tid * kPer + k] = o;
+                        table[tid * kPer + k] = o;
+                    }
+                    if (tid == 0) table[kGraphBins] = K;
+                }
+                __syncthreads();
+                float4 *xraw = reinterpret_cast<float4 *>(gk + 2 * (size_t)region);
+                int *xidx = s.xidx + reg;
+                int *gcnt = s.gcnt + reg, *gedge = s.gedge + reg * kGraphEdges;
+                for (int i = tid; i < K; i += kSegThreads) {
+                    const float4 c4 = gbox[i];
+                    const int pos = atomicAdd(&s_cur[bin_of(c4)], 1);
+                    xidx[pos] = i;
+                    xraw[pos] = c4;
+                    gcnt[pos] = 0;
+                    gedge[(size_t)pos * kGraphEdges] = 0x7fffffff;
+                }
+                if (tid == 0) {
+                    s.glist[g.table] = seg;
+                    s.gseg[seg] = g;
+                    s.seg_kept[seg] = 0;
+                    s.seg_pairs[seg] = 0u;
+                    s.seg_ties[seg] = 0u;
+                    s.ctrl[0] = 1;
+                }
+                return;
+            }
+            __syncthreads();   // not eligible: the scratch goes back to the chunked path below
+        }
         // ---- x-order of the candidates: counting sort by (stripe, width class, position inside
         // the stripe) of the box centre along the pruning axis into 8 x 32 buckets (LDS
         // histogram; the order inside a bucket is whatever the atomics give, which only changes
@@ -1971,6 +2161,13 @@ struct Workspace {
     int *seg_region;
     unsigned int *seg_pairs;
     unsigned int *seg_ties;
+    // graph path (YOLOv3 mode only)
+    int *gcnt;
+    int *gedge;
+    GraphSeg *gseg;
+    int *bin_tables;
+    int *glist;
+    int *ctrl;
 };
 
 template <class T>
@@ -1982,7 +2179,7 @@ size_t carve_one(char *base, size_t off, size_t count, T **out)
 }
 
 // Lays the scratch arrays out inside `base` (or just sizes them when base is null).
-size_t carve(void *base_v, size_t slots, size_t tiles, size_t n_seg, Workspace *w)
+size_t carve(void *base_v, size_t slots, size_t tiles, size_t n_seg, Workspace *w, bool graph = true)
 {
     char *base = static_cast<char *>(base_v);
     Workspace dummy;
@@ -2005,6 +2202,22 @@ size_t carve(void *base_v, size_t slots, size_t tiles, size_t n_seg, Workspace *
     off = carve_one(base, off, n_seg, &w->seg_region);
     off = carve_one(base, off, n_seg, &w->seg_pairs);
     off = carve_one(base, off, n_seg, &w->seg_ties);
+    off = carve_one(base, off, 16, &w->ctrl);
+    w->gcnt = nullptr;
+    w->gedge = nullptr;
+    w->gseg = nullptr;
+    w->bin_tables = nullptr;
+    w->glist = nullptr;
+    if (graph) {
+        // every graph segment has more than kGraphMin candidates of its own, which bounds how
+        // many bin tables a launch can hand out
+        const size_t n_tables = n_seg < slots / kGraphMin + 1 ? n_seg : slots / kGraphMin + 1;
+        off = carve_one(base, off, slots, &w->gcnt);
+        off = carve_one(base, off, slots * kGraphEdges, &w->gedge);
+        off = carve_one(base, off, n_seg, &w->gseg);
+        off = carve_one(base, off, n_tables * (kGraphBins + 1), &w->bin_tables);
+        off = carve_one(base, off, n_tables, &w->glist);
+    }
     return (off + kAlign - 1) / kAlign * kAlign;
 }
 
@@ -2130,6 +2343,12 @@ SegArgs make_seg_args(const Workspace &w, const YpParams *p, int spi, int tpi, i
     s.seg_region = w.seg_region;
     s.seg_pairs = w.seg_pairs;
     s.seg_ties = w.seg_ties;
+    s.gseg = w.gseg;
+    s.bin_tables = w.bin_tables;
+    s.glist = w.glist;
+    s.gcnt = w.gcnt;
+    s.gedge = w.gedge;
+    s.ctrl = w.ctrl;
     s.dbg = g_dbg;
     return s;
 }
@@ -2142,9 +2361,11 @@ struct ProfileState {
     bool on = false;
     int max_calls = 0;
     int calls = 0;
-    hipEvent_t *ev = nullptr;        // 6 per call: (start, stop) x (front, nms, gather)
+    hipEvent_t *ev = nullptr;        // kProfEvents per call: (start, stop) x (front, nms, gather,
+                                     // graph pairs, graph resolve)
     unsigned char *launched = nullptr;  // per call: bit k set when kernel k was launched
 };
+constexpr int kProfKernels = 5, kProfEvents = 2 * kProfKernels;
 ProfileState g_prof;
 
 inline bool prof_active() { return g_prof.on && g_prof.calls < g_prof.max_calls; }
@@ -2152,7 +2373,7 @@ inline bool prof_active() { return g_prof.on && g_prof.calls < g_prof.max_calls;
 inline hipEvent_t prof_ev(int k, int end)
 {
     g_prof.launched[g_prof.calls] |= (unsigned char)(1u << k);
-    return g_prof.ev[6 * g_prof.calls + 2 * k + end];
+    return g_prof.ev[kProfEvents * g_prof.calls + 2 * k + end];
 }
 
 inline void prof_next()
@@ -2160,7 +2381,7 @@ inline void prof_next()
     if (prof_active()) ++g_prof.calls;
 }
 
-// k: 0 front, 1 segment NMS, 2 gather.
+// k: 0 front, 1 segment NMS, 2 gather, 3 graph pairs, 4 graph resolve.
 #define YP_LAUNCH(k, kernel, grid, block, lds, st, ...)                                          \
     do {                                                                                         \
         if (prof_active())                                                                       \
@@ -2185,6 +2406,40 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
     s.max_out = p->max_out;
     if (stages & 2)
         YP_LAUNCH(1, k_segment_nms<YP_MODE_YOLOV3>, dim3(n_seg), dim3(kSegThreads), 0, st, s);
+    if ((stages & 2) && w.gseg && spi > kGraphMin) {
+        // segments the NMS kernel handed to the graph path (none: both kernels leave at once)
+        GraphArgs ga = {};
+        ga.per_class = 1;
+        ga.C = p->num_classes;
+        ga.spi = spi;
+        ga.max_out = p->max_out;
+        ga.thr = p->nms_thr;
+        ga.gseg = w.gseg;
+        ga.bin_tables = w.bin_tables;
+        ga.xraw = reinterpret_cast<const float4 *>(w.gkeys);
+        ga.xidx = w.xidx;
+        ga.status = w.removed;
+        ga.gcnt = w.gcnt;
+        ga.gedge = w.gedge;
+        ga.sslot = w.sslot;
+        ga.seg_region = w.seg_region;
+        ga.glist = w.glist;
+        ga.kept_slot = w.kept_slot;
+        ga.seg_kept = w.seg_kept;
+        ga.seg_pairs = w.seg_pairs;
+        ga.seg_ties = w.seg_ties;
+        // pair tests: a fixed number of workgroups that share out the batches of all graph
+        // segments; resolve: one workgroup per graph segment (those beyond their number leave)
+        const long long slots_all = (long long)n_seg / p->num_classes * spi;
+        long long n_tables = slots_all / kGraphMin + 1;
+        n_tables = n_tables < n_seg ? n_tables : n_seg;
+        long long n_wg = slots_all / 64 / 2 + 1;
+        n_wg = n_wg > 1280 ? 1280 : n_wg;
+        YP_LAUNCH(3, k_graph_pairs<YP_MODE_YOLOV3>, dim3((unsigned)n_wg), dim3(kGraphThreads), 0, st, ga,
+                  w.ctrl);
+        YP_LAUNCH(4, k_graph_resolve<YP_MODE_YOLOV3>, dim3((unsigned)n_tables), dim3(kSegThreads), 0, st, ga,
+                  w.ctrl);
+    }
     GatherArgs g = {};
     g.n_seg = n_seg;
     g.C = p->num_classes;
@@ -2309,7 +2564,7 @@ size_t yp_detect_yolov3_workspace_bytes(const YpHead *heads, int n_heads, int ba
     const long long spi = (long long)ha.tpi * kFrontCells * amax;
     if (!slots_fit(batch, spi)) return 0;
     return carve(nullptr, (size_t)batch * spi, (size_t)batch * ha.tpi,
-                 (size_t)batch * num_classes, nullptr);
+                 (size_t)batch * num_classes, nullptr, true);
 }
 
 // Shared body of yp_detect_yolov3 (one set) and yp_detect_yolov3_multi.
@@ -2335,10 +2590,10 @@ static int detect_v3_sets(const YpHead *heads, int n_heads, int n_sets, const Yp
     const size_t slots = (size_t)images * spi, tiles = (size_t)images * ha.tpi;
     const size_t n_seg = (size_t)images * params->num_classes;
     Workspace w;
-    const size_t need = carve(nullptr, slots, tiles, n_seg, nullptr);
+    const size_t need = carve(nullptr, slots, tiles, n_seg, nullptr, true);
     if (!workspace_ok(d_workspace, workspace_bytes, need)) return YP_ERR_WORKSPACE;
-    carve(d_workspace, slots, tiles, n_seg, &w);
-    CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, ha.tpi, ts};
+    carve(d_workspace, slots, tiles, n_seg, &w, true);
+    CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, ha.tpi, ts, w.ctrl};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ha.tpi, params->batch, n_sets), block(kFrontCells * amax);
     float t_lo, t_hi;
@@ -2480,7 +2735,7 @@ int yp_write_results(const float *d_rows, int rows_per_image, const YpParams *pa
     const size_t need = yp_rows_workspace_bytes(params->batch, rows_per_image, params->num_classes);
     if (!workspace_ok(d_workspace, workspace_bytes, need)) return YP_ERR_WORKSPACE;
     carve(d_workspace, slots, tiles, (size_t)params->batch * params->num_classes, &w);
-    CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile};
+    CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile, w.ctrl};
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = yp_tile_lds_bytes(5 + params->num_classes);
     if (lds)
@@ -2523,7 +2778,7 @@ int yp_detect_reference(const YpHead *head, const YpParams *params, float *d_out
     Workspace w;
     carve(d_workspace, (size_t)params->batch * spi, (size_t)params->batch * tpi,
           (size_t)params->batch, &w);
-    CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile};
+    CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile, w.ctrl};
     AnchorTable at = {};
     for (int i = 0; i < 2 * head->num_anchors; ++i) at.anc[i] = head->anchors[i];
     hipStream_t st = (hipStream_t)stream;
@@ -2565,7 +2820,7 @@ int yp_filter_boxes_reference(const float *d_center, const float *d_wh, const fl
     Workspace w;
     carve(d_workspace, (size_t)params->batch * spi, (size_t)params->batch * tpi,
           (size_t)params->batch, &w);
-    CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile};
+    CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile, w.ctrl};
     hipStream_t st = (hipStream_t)stream;
     YP_LAUNCH(0, k_front_split_ref, dim3(tpi, params->batch), dim3(kRowTile), 0, st, d_center, d_wh,
               d_obj, d_cls, rows_per_image, params->num_classes, cb, params->conf_thr, params->im_h,
@@ -2592,9 +2847,9 @@ int yp_debug_set_front_stamps(void *d_buf)
 int yp_profile_start(int max_calls)
 {
     if (max_calls <= 0 || max_calls > (1 << 16) || g_prof.on) return YP_ERR_ARG;
-    g_prof.ev = new hipEvent_t[6 * (size_t)max_calls];
+    g_prof.ev = new hipEvent_t[kProfEvents * (size_t)max_calls];
     g_prof.launched = new unsigned char[(size_t)max_calls]();
-    for (int i = 0; i < 6 * max_calls; ++i) {
+    for (int i = 0; i < kProfEvents * max_calls; ++i) {
         const hipError_t e = hipEventCreate(&g_prof.ev[i]);
         if (e != hipSuccess) return (int)e;
     }
@@ -2604,35 +2859,45 @@ int yp_profile_start(int max_calls)
     return YP_OK;
 }
 
-int yp_profile_stop(double *front_ms, double *nms_ms, double *gather_ms, int *calls)
+int yp_profile_stop_ex(double *ms, int *calls)
 {
-    if (!g_prof.on || !front_ms || !nms_ms || !gather_ms || !calls) return YP_ERR_ARG;
+    if (!g_prof.on || !ms || !calls) return YP_ERR_ARG;
     g_prof.on = false;
-    double acc[3] = {0.0, 0.0, 0.0};
-    int cnt[3] = {0, 0, 0};
+    double acc[kProfKernels] = {};
     int rc = YP_OK;
     for (int c = 0; c < g_prof.calls && rc == YP_OK; ++c)
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < kProfKernels; ++k) {
             if (!(g_prof.launched[c] & (1u << k))) continue;
-            float ms = 0.f;
-            hipError_t e = hipEventSynchronize(g_prof.ev[6 * c + 2 * k + 1]);
+            float t = 0.f;
+            hipError_t e = hipEventSynchronize(g_prof.ev[kProfEvents * c + 2 * k + 1]);
             if (e == hipSuccess)
-                e = hipEventElapsedTime(&ms, g_prof.ev[6 * c + 2 * k], g_prof.ev[6 * c + 2 * k + 1]);
+                e = hipEventElapsedTime(&t, g_prof.ev[kProfEvents * c + 2 * k],
+                                        g_prof.ev[kProfEvents * c + 2 * k + 1]);
             if (e != hipSuccess) { rc = (int)e; break; }
-            acc[k] += ms;
-            ++cnt[k];
+            acc[k] += t;
         }
     *calls = g_prof.calls;
-    *front_ms = cnt[0] ? acc[0] / cnt[0] : 0.0;
-    *nms_ms = cnt[1] ? acc[1] / cnt[1] : 0.0;
-    *gather_ms = cnt[2] ? acc[2] / cnt[2] : 0.0;
-    for (int i = 0; i < 6 * g_prof.max_calls; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+    // averages per CALL (a kernel a call did not launch counts as zero time)
+    for (int k = 0; k < kProfKernels; ++k) ms[k] = g_prof.calls ? acc[k] / g_prof.calls : 0.0;
+    for (int i = 0; i < kProfEvents * g_prof.max_calls; ++i) (void)hipEventDestroy(g_prof.ev[i]);
     delete[] g_prof.ev;
     delete[] g_prof.launched;
     g_prof.ev = nullptr;
     g_prof.launched = nullptr;
     g_prof.max_calls = g_prof.calls = 0;
     return rc;
+}
+
+int yp_profile_stop(double *front_ms, double *nms_ms, double *gather_ms, int *calls)
+{
+    if (!front_ms || !nms_ms || !gather_ms) return YP_ERR_ARG;
+    double ms[kProfKernels];
+    const int rc = yp_profile_stop_ex(ms, calls);
+    if (rc != YP_OK) return rc;
+    *front_ms = ms[0];
+    *nms_ms = ms[1] + ms[3] + ms[4];
+    *gather_ms = ms[2];
+    return YP_OK;
 }
 
 int yp_bbox_iou(const float *d_box1, const float *d_boxes2, int m, int row_stride, float *d_out,

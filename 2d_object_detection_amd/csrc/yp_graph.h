@@ -1,0 +1,521 @@
+// yp_graph.h -- greedy NMS of LARGE segments as a dependency graph, spread over many
+// workgroups.  Included by yolopost.hip inside its anonymous namespace (it uses that file's
+// wave helpers, suppress_words and SegArgs).
+//
+// Greedy NMS over rows sorted by score keeps row i iff no KEPT row j < i suppresses it.  That
+// is a recurrence over the graph "j suppresses i, j ranked before i", and it can be evaluated
+// without walking the rows in order:
+//
+//   k_segment_nms   (one workgroup per segment, the existing kernel) gathers and sorts the
+//                   segment as before; for a large segment it then only builds a spatial index
+//                   -- the boxes binned by (size class, cell row, cell column) of their centre
+//                   with a counting sort -- and leaves.
+//   k_graph_pairs   many workgroups per segment.  A workgroup takes 64 boxes that are neighbours
+//                   in the index ("columns", one per lane), looks up the bins of their own and of
+//                   larger size classes whose boxes can overlap any of them, stages those "rows"
+//                   in LDS and tests every row against the 64 columns with the same staged,
+//                   division-free test as the other paths.  For every box it records (atomics)
+//                   how many earlier-ranked boxes suppress it, the earliest of them and up to
+//                   seven more.
+//   k_graph_resolve one workgroup per segment iterates  "a suppressor is KEPT -> SUPPRESSED;
+//                   all suppressors SUPPRESSED -> KEPT"  over the undecided columns until none is
+//                   left (the lowest-ranked undecided column can always be decided, so at most
+//                   2K rounds; a handful in practice), re-deriving a column's suppressor list
+//                   from the index when the recorded ones are used up, and emits the kept rows in
+//                   rank order.
+//
+// Nothing is skipped that could change a verdict: a bin is left out only when every box in it
+// has zero intersection with every column of the batch (centres further apart than the half
+// sizes allow, with slack), or belongs to a size class whose boxes cannot reach the threshold
+// against the batch's classes (IoU <= min(w_i/w_j, h_i/h_j) for w_i <= w_j ...).  Both need a
+// positive threshold inside the guard-band range and boxes with positive width and height;
+// segments that do not qualify stay on the chunked path of k_segment_nms.
+#pragma once
+
+constexpr int kGraphMin = YP_GRAPH_MIN;   // segments with more candidates take this path
+constexpr int kGraphBins = 4096;          // bins of a segment's index (all classes together)
+constexpr int kGraphClasses = 8;          // size classes (powers of two of max(width, height))
+constexpr int kGraphEdges = 8;            // recorded suppressors per column (the earliest + 7)
+constexpr int kGraphRowTile = 256;        // rows a wave stages in LDS per pass
+constexpr int kGraphThreads = 256;        // k_graph_pairs workgroup
+constexpr int kGraphWaves = kGraphThreads / 64;
+constexpr int kGraphRanges = 64;          // bin ranges a wave looks up per pass
+
+enum { kUndecided = 0, kKept = 1, kSuppressed = 2 };
+
+// Index of one large segment (written by k_segment_nms, read by the two kernels below).
+struct GraphSeg {
+    int K;          // candidates; 0 = the segment did not take this path
+    int table;      // its bin table in the pool: kGraphBins + 1 offsets
+    int e_min;      // biased exponent of the smallest box size of the segment
+    int d;          // classes further apart than this cannot reach the threshold
+    float x0, y0;   // smallest centre coordinates
+    float margin;   // slack added to every reach (2 px + rounding of the coordinates)
+    int n_bins;
+    float invx[kGraphClasses];     // 1 / cell width and 1 / cell height of the class's grid
+    float invy[kGraphClasses];
+    float half[kGraphClasses];     // upper bound of half the box size in the class
+    int nx[kGraphClasses], ny[kGraphClasses], base[kGraphClasses];
+};
+
+struct GraphArgs {
+    int per_class, C, spi, max_out;
+    float thr;
+    const GraphSeg *gseg;        // [n_seg]
+    const int *bin_tables;       // pool of (kGraphBins + 1)-entry offset tables
+    const float4 *xraw;          // [B*spi] prepared corners in index order (reuses the key area)
+    const int *xidx;             // [B*spi] rank of the box at an index position
+    unsigned char *status;       // [B*spi] per rank: kUndecided / kKept / kSuppressed
+    int *gcnt;                   // [B*spi] per index position: suppressors found
+    int *gedge;                  // [B*spi * kGraphEdges] per index position: their ranks
+    const int *sslot;            // [B*spi] rank -> candidate slot
+    const int *seg_region;       // [n_seg]
+    const int *glist;            // graph segments of the launch, by the order their tables were taken
+    int *kept_slot;              // [B*spi]
+    int *seg_kept;               // [n_seg]
+    unsigned int *seg_pairs;     // [n_seg]
+    unsigned int *seg_ties;      // [n_seg]
+};
+
+// Size of a box for the class test: the larger of the width and height terms the IoU uses.
+template <int MODE>
+__device__ __forceinline__ float graph_box_size(const float4 &c)
+{
+    const float plus1 = MODE == YP_MODE_YOLOV3 ? 1.0f : 0.0f;
+    const float w = c.z - c.x + plus1, h = c.w - c.y + plus1;
+    return w > h ? w : h;
+}
+
+__device__ __forceinline__ int graph_class(float size, int e_min)
+{
+    const int e = (int)((__float_as_uint(size) >> 23) & 255u) - e_min;
+    return e < 0 ? 0 : (e >= kGraphClasses ? kGraphClasses - 1 : e);
+}
+
+// Cell index of a coordinate along one axis of a class grid: monotone in v (subtraction of a
+// constant, multiplication by a non-negative constant, floor, clamp), which is what makes "every
+// box whose centre lies in [a, b] sits in a cell of [cell(a), cell(b)]" hold without rounding
+// caveats.  Cells are laid out row by row, every other row backwards, so that consecutive
+// index positions stay neighbours in the plane across the end of a row.
+__device__ __forceinline__ int graph_cell(float v, float origin, float inv, int n)
+{
+    float t = (v - origin) * inv;
+    t = t > 0.0f ? t : 0.0f;                  // (also a NaN)
+    const float top = (float)(n - 1);
+    t = t < top ? t : top;
+    return (int)t;
+}
+
+__device__ __forceinline__ float wave_min_f(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = vmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = vmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+constexpr int kGraphBuf = kGraphRowTile + 64;   // useful rows a wave collects before testing
+
+// Per-wave LDS of a walk.
+struct GraphWaveShared {
+    float4 row[kGraphBuf];          // useful rows: prepared corners
+    float area[kGraphBuf];          // their area terms
+    int rank[kGraphBuf];            // their ranks
+    int pc[kGraphBuf];              // index position | size class << 24
+    int rbeg[kGraphRanges];         // bin ranges of the current pass: first index position
+    int rpre[kGraphRanges + 1];     // exclusive prefix of their lengths
+};
+
+// Records "the row ranked `suppressor` suppresses the box at index position `target`": the
+// count, the earliest suppressor and the first kGraphEdges-1 that arrive (any order).
+__device__ __forceinline__ void graph_record(int *gcnt, int *gedge, int target, int suppressor)
+{
+    const int k = atomicAdd(&gcnt[target], 1);
+    if (k < kGraphEdges - 1) gedge[(size_t)target * kGraphEdges + 1 + k] = suppressor;
+    atomicMin(&gedge[(size_t)target * kGraphEdges], suppressor);
+}
+
+// One batch: the 64 columns held by the lanes (corners `cj`, rank `my_rank`, index position
+// `my_pos`, valid where `live`) against the rows of the index that can overlap any of them.
+//
+// REBUILD == false (k_graph_pairs): every unordered pair of the segment has to be tested once,
+// so the batch looks at its own size class and the LARGER ones within reach -- small boxes are
+// many and dense, and 64 neighbours of them reach few larger boxes, whereas 64 large boxes
+// between them would reach every small one.  A suppressing pair is recorded at its later-ranked
+// box with graph_record: at the column when the row is ranked earlier, at the row when the
+// column is and the row's class is larger (within one class the pair comes up a second time with
+// the roles swapped).  The walk is shared by the `n_split` waves of a workgroup: wave
+// `split` takes every n_split-th tile of candidate rows.
+//
+// REBUILD == true (k_graph_resolve): the columns need ALL their suppressors that are not
+// suppressed themselves: smaller and larger classes, rows with status kSuppressed left out.
+// Per lane the count is returned, the ranks go to `edge_out` (the earliest in [0], then up to
+// kGraphEdges-1 in the order found), and kept_hit tells that one of them is already kept.
+//
+// Candidate rows are looked at by one lane each when they are fetched: a row that cannot touch
+// the batch's bounding box, whose class is out of order for the pair rule, or that is already
+// suppressed (REBUILD) is dropped there; the others are packed into LDS, and whenever enough
+// have gathered they are tested four at a time (uniform) against the 64 columns.
+template <int MODE, bool REBUILD>
+__device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, const float4 *xraw,
+                                          const int *xidx, const unsigned char *status, int *gcnt,
+                                          int *gedge, const float4 &cj, int my_rank, int my_pos,
+                                          bool live, const YpThr &thr, GraphWaveShared &ws, int split,
+                                          int n_split, int *edge_out, unsigned int &pairs,
+                                          unsigned int &ties, bool &kept_hit)
+{
+    const int lane = threadIdx.x & 63;
+    const YpBox bj = {cj.x, cj.y, cj.z, cj.w};
+    const YpPrep pj = yp_prep<MODE>(bj);
+    // classes and extent of the batch (uniform)
+    const int my_class = graph_class(graph_box_size<MODE>(cj), gs.e_min);
+    const int cA = wave_min_i(live ? my_class : kGraphClasses), cB = wave_max_i(live ? my_class : -1);
+    const float inf = __builtin_inff();
+    const float bxlo = wave_min_f(live ? pj.lo0 : inf), bxhi = wave_max_f(live ? pj.hi0 : -inf);
+    const float bylo = wave_min_f(live ? pj.lo1 : inf), byhi = wave_max_f(live ? pj.hi1 : -inf);
+    const int n_live = __popcll(__ballot(live));
+    int cnt = 0, first = 0x7fffffff;
+    kept_hit = false;
+    if (cB < 0) return 0;
+    const int c_first = REBUILD ? cA - gs.d : cA;
+    const int c_lo = c_first > 0 ? c_first : 0;
+    const int c_hi = cB + gs.d < kGraphClasses - 1 ? cB + gs.d : kGraphClasses - 1;
+
+    int n_buf = 0;      // useful rows waiting in LDS (uniform)
+    // test the waiting rows against the columns, four (uniform) rows at a time
+    auto flush = [&]() {
+        // pad to a multiple of four with rows that cannot record anything
+        if (lane < 4) {
+            const int q = n_buf + lane;
+            if (q < ((n_buf + 3) & ~3)) {
+                ws.row[q] = make_float4(3e38f, 3e38f, 3e38f, 3e38f);
+                ws.area[q] = 1.0f;
+                ws.rank[q] = 0x7fffffff;
+                ws.pc[q] = 0;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int r0 = 0; r0 < n_buf; r0 += 4) {
+            float4 ci[4];
+            float ai[4];
+            int rk[4], pc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ci[u] = ws.row[r0 + u];
+                ai[u] = ws.area[r0 + u];
+                rk[u] = ws.rank[r0 + u];
+                pc[u] = ws.pc[r0 + u];
+            }
+            u64 words[4];
+            suppress_words<MODE, 4>(pj, live, ci, ai, thr, words, ties);
+            if ((words[0] | words[1] | words[2] | words[3]) == 0ull) continue;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (words[u] == 0ull) continue;
+                const bool sup = (words[u] >> lane) & 1ull;
+                if (REBUILD) {
+                    // only rows ranked before the column count (this also drops the column itself)
+                    if (sup && rk[u] < my_rank) {
+                        if (cnt < kGraphEdges - 1) edge_out[1 + cnt] = rk[u];
+                        first = rk[u] < first ? rk[u] : first;
+                        ++cnt;
+                        if (status[rk[u]] == kKept) kept_hit = true;
+                    }
+                } else if (sup) {
+                    const int rc = pc[u] >> 24;
+                    if (rk[u] < my_rank) {
+                        if (rc >= my_class) graph_record(gcnt, gedge, my_pos, rk[u]);
+                    } else if (rk[u] > my_rank && rc > my_class) {
+                        graph_record(gcnt, gedge, pc[u] & 0xffffff, my_rank);
+                    }
+                }
+            }
+        }
+        if (lane == 0) pairs += (unsigned int)(n_buf * n_live);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the buffer is refilled
+        n_buf = 0;
+    };
+
+    // ranges = (class, cell row) pairs in reach, each a run of consecutive cells = one contiguous
+    // run of index positions; numbered class-major and handed to the lanes 64 at a time
+    int n_ranges = 0;
+    for (int c = c_lo; c <= c_hi; ++c) {
+        if (gs.nx[c] <= 0) continue;
+        const float reach = gs.half[c] + gs.margin;
+        const int iy0 = graph_cell(bylo - reach, gs.y0, gs.invy[c], gs.ny[c]);
+        const int iy1 = graph_cell(byhi + reach, gs.y0, gs.invy[c], gs.ny[c]);
+        n_ranges += iy1 - iy0 + 1;
+    }
+    int tile_no = 0;     // candidate tiles of the batch, numbered over all passes
+    for (int g0 = 0; g0 < n_ranges; g0 += kGraphRanges) {
+        // lane l: range g0 + l
+        int beg = 0, len = 0;
+        {
+            int want = g0 + lane, seen = 0;
+            for (int c = c_lo; c <= c_hi; ++c) {
+                if (gs.nx[c] <= 0) continue;
+                const float reach = gs.half[c] + gs.margin;
+                const int iy0 = graph_cell(bylo - reach, gs.y0, gs.invy[c], gs.ny[c]);
+                const int iy1 = graph_cell(byhi + reach, gs.y0, gs.invy[c], gs.ny[c]);
+                const int n = iy1 - iy0 + 1;
+                if (want >= seen && want < seen + n) {
+                    const int iy = iy0 + (want - seen);
+                    const int ix0 = graph_cell(bxlo - reach, gs.x0, gs.invx[c], gs.nx[c]);
+                    const int ix1 = graph_cell(bxhi + reach, gs.x0, gs.invx[c], gs.nx[c]);
+                    const int b0 = gs.base[c] + iy * gs.nx[c];
+                    const int ca = (iy & 1) ? gs.nx[c] - 1 - ix1 : ix0;     // (odd rows run backwards)
+                    const int cb = (iy & 1) ? gs.nx[c] - 1 - ix0 : ix1;
+                    beg = off[b0 + ca];
+                    len = off[b0 + cb + 1] - beg;
+                }
+                seen += n;
+            }
+        }
+        const int incl = wave_inclusive_scan(len, lane);
+        ws.rbeg[lane] = beg;
+        ws.rpre[lane + 1] = incl;
+        if (lane == 0) ws.rpre[0] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int n_rows = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
+        for (int t0 = 0; t0 < n_rows; t0 += kGraphRowTile, ++tile_no) {
+            if (tile_no % n_split != split) continue;
+            const int fill = n_rows - t0 < kGraphRowTile ? n_rows - t0 : kGraphRowTile;
+            // fetch: element e of the concatenated ranges -> its range by bisection of the
+            // prefix; all loads of the tile are in flight together
+            int src[kGraphRowTile / 64];
+#pragma unroll
+            for (int k = 0; k < kGraphRowTile / 64; ++k) {
+                const int e = t0 + k * 64 + lane;
+                int lo = 0, hi = kGraphRanges - 1;     // largest l with rpre[l] <= e
+#pragma unroll
+                for (int st = 0; st < 6; ++st) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (ws.rpre[mid] <= e) lo = mid; else hi = mid - 1;
+                }
+                src[k] = k * 64 + lane < fill ? ws.rbeg[lo] + (e - ws.rpre[lo]) : 0;
+            }
+            float4 c4[kGraphRowTile / 64];
+            int r4[kGraphRowTile / 64];
+#pragma unroll
+            for (int k = 0; k < kGraphRowTile / 64; ++k) {
+                c4[k] = xraw[src[k]];
+                r4[k] = xidx[src[k]];
+            }
+            // sift and pack
+#pragma unroll
+            for (int k = 0; k < kGraphRowTile / 64; ++k) {
+                const int rc = graph_class(graph_box_size<MODE>(c4[k]), gs.e_min);
+                bool useful = k * 64 + lane < fill && !(c4[k].z + gs.margin < bxlo) &&
+                              !(c4[k].x - gs.margin > bxhi) && !(c4[k].w + gs.margin < bylo) &&
+                              !(c4[k].y - gs.margin > byhi);
+                if (!REBUILD) useful = useful && rc >= cA;
+                if (REBUILD && useful) useful = status[r4[k]] != kSuppressed;
+                const u64 m = __ballot(useful);
+                if (useful) {
+                    const int q = n_buf + __popcll(m & lanes_below(lane));
+                    const YpBox bi = {c4[k].x, c4[k].y, c4[k].z, c4[k].w};
+                    ws.row[q] = c4[k];
+                    ws.area[q] = yp_prep<MODE>(bi).area;
+                    ws.rank[q] = r4[k];
+                    ws.pc[q] = src[k] | (rc << 24);
+                }
+                n_buf += __popcll(m);
+            }
+            if (n_buf > 64) flush();     // (room for the next tile: kGraphBuf - 64 >= a tile)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();       // the next pass overwrites the ranges
+    }
+    if (n_buf > 0) flush();
+    if (REBUILD) edge_out[0] = first;
+    return cnt;
+}
+
+// Pair tests of every graph segment of the launch.  A workgroup takes one batch at a time, its
+// waves share the batch's row tiles; the workgroups walk the list of graph segments and take
+// the batches blockIdx.x, blockIdx.x + gridDim.x, ... of each (rotated from segment to segment
+// so that short segments do not all land on the first workgroups).
+template <int MODE>
+__global__ __launch_bounds__(kGraphThreads) void k_graph_pairs(GraphArgs a, const int *ctrl)
+{
+    __shared__ GraphWaveShared s_ws[kGraphWaves];
+    __shared__ GraphSeg s_gs;
+    const int n_graph = ctrl[1];                    // graph segments of this launch
+    if (n_graph == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const YpThr thr = yp_make_thr(a.thr);
+    GraphWaveShared &ws = s_ws[wave];
+    for (int t = 0; t < n_graph; ++t) {
+        const int seg = a.glist[t];
+        __syncthreads();                            // everyone is done with the previous s_gs
+        {
+            const int *src = reinterpret_cast<const int *>(a.gseg + seg);
+            int *dst = reinterpret_cast<int *>(&s_gs);
+            for (int i = threadIdx.x; i < (int)(sizeof(GraphSeg) / 4); i += kGraphThreads) dst[i] = src[i];
+        }
+        __syncthreads();
+        const int K = s_gs.K;
+        const int b = a.per_class ? seg / a.C : seg;
+        const size_t reg = (size_t)b * a.spi + a.seg_region[seg];
+        const int *off = a.bin_tables + (size_t)s_gs.table * (kGraphBins + 1);
+        const float4 *xraw = a.xraw + reg;
+        const int *xidx = a.xidx + reg;
+        unsigned int pairs = 0, ties = 0;
+        const int n_batches = (K + 63) >> 6;
+        const int start = (int)((blockIdx.x + (unsigned)t * 37u) % gridDim.x);
+        for (int batch = start; batch < n_batches; batch += gridDim.x) {
+            const int p = batch * 64 + lane;
+            const bool live = p < K;
+            const float4 cj = xraw[live ? p : K - 1];
+            const int my_rank = live ? xidx[p] : -1;
+            bool kept_hit;
+            graph_walk<MODE, false>(s_gs, off, xraw, xidx, nullptr, a.gcnt + reg, a.gedge + reg * kGraphEdges,
+                                    cj, my_rank, p, live, thr, ws, wave, kGraphWaves, nullptr, pairs, ties,
+                                    kept_hit);
+        }
+        if (lane == 0 && pairs) atomicAdd(&a.seg_pairs[seg], pairs);
+        if (lane == 0 && ties) atomicAdd(&a.seg_ties[seg], ties);
+    }
+}
+
+// Keep set of one graph segment from the recorded suppressors, then its kept rows in rank
+// order.  One workgroup per graph segment of the launch.
+template <int MODE>
+__global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, const int *ctrl)
+{
+    __shared__ GraphWaveShared s_ws[kSegWaves];
+    __shared__ int s_edge[kSegWaves][64][kGraphEdges];
+    __shared__ GraphSeg s_gs;
+    __shared__ int s_undecided, s_redo;
+    __shared__ u64 s_bal[kSegWaves];
+    if ((int)blockIdx.x >= ctrl[1]) return;
+    const int seg = a.glist[blockIdx.x];
+    {
+        const int *src = reinterpret_cast<const int *>(a.gseg + seg);
+        int *dst = reinterpret_cast<int *>(&s_gs);
+        for (int i = threadIdx.x; i < (int)(sizeof(GraphSeg) / 4); i += kSegThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int K = s_gs.K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = a.per_class ? seg / a.C : seg;
+    const size_t reg = (size_t)b * a.spi + a.seg_region[seg];
+    const int *off = a.bin_tables + (size_t)s_gs.table * (kGraphBins + 1);
+    const float4 *xraw = a.xraw + reg;
+    const int *xidx = a.xidx + reg;
+    unsigned char *status = a.status + reg;
+    int *gcnt = a.gcnt + reg;
+    int *gedge = a.gedge + reg * kGraphEdges;
+    const YpThr thr = yp_make_thr(a.thr);
+    unsigned int pairs = 0, ties = 0;
+    const int n_batches = (K + 63) >> 6;
+    // Rounds.  Statuses only ever go from undecided to their final value, so reading one that
+    // another wave has just written is as good as reading it a round later.  Every round
+    // decides at least the lowest-ranked undecided column (all its suppressors are decided), or
+    // re-derives its list and decides it in the next: the loop ends after at most 2K rounds.
+    for (int round = 0; round < 2 * K + 2; ++round) {
+        if (tid == 0) { s_undecided = 0; s_redo = 0; }
+        __syncthreads();
+        int undecided = 0, redo = 0;
+        for (int p = tid; p < K; p += kSegThreads) {
+            const int r = xidx[p];
+            if (status[r] != kUndecided) continue;
+            const int cnt = gcnt[p];
+            if (cnt == 0) { status[r] = kKept; continue; }
+            if (cnt < 0) { ++redo; ++undecided; continue; }       // list used up: re-derive below
+            const int4 *e4 = reinterpret_cast<const int4 *>(gedge + (size_t)p * kGraphEdges);
+            const int4 ea = e4[0], eb = e4[1];
+            const int e[kGraphEdges] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+            const int listed = cnt < kGraphEdges - 1 ? cnt : kGraphEdges - 1;
+            bool any_kept = false, all_sup = true;
+#pragma unroll
+            for (int k = 0; k < kGraphEdges; ++k) {
+                if (k <= listed) {       // [0] the earliest, [1..listed] the recorded ones
+                    const int st = status[e[k]];
+                    any_kept = any_kept || st == kKept;
+                    all_sup = all_sup && st == kSuppressed;
+                }
+            }
+            if (any_kept) status[r] = kSuppressed;
+            else if (all_sup && cnt <= kGraphEdges - 1) status[r] = kKept;
+            else {
+                ++undecided;
+                if (all_sup) { gcnt[p] = -1; ++redo; }               // more suppressors than recorded
+            }
+        }
+        if (undecided) atomicAdd(&s_undecided, undecided);
+        if (redo) atomicAdd(&s_redo, redo);
+        __syncthreads();
+        if (s_undecided == 0) break;
+        if (s_redo != 0) {
+            // re-derive the suppressor lists of the flagged columns from the index, leaving out
+            // rows that are suppressed by now; a kept suppressor settles the column on the spot
+            for (int batch = wave; batch < n_batches; batch += kSegWaves) {
+                const int p = batch * 64 + lane;
+                const bool in = p < K;
+                const int my_rank = in ? xidx[p] : -1;
+                const bool need = in && gcnt[p] < 0 && status[my_rank] == kUndecided;
+                if (__ballot(need) == 0ull) continue;
+                const float4 cj = xraw[in ? p : K - 1];
+                bool kept_hit;
+                int *le = s_edge[wave][lane];
+                const int cnt = graph_walk<MODE, true>(s_gs, off, xraw, xidx, status, nullptr, nullptr, cj,
+                                                       my_rank, p, need, thr, s_ws[wave], 0, 1, le, pairs,
+                                                       ties, kept_hit);
+                if (need) {
+                    if (kept_hit) status[my_rank] = kSuppressed;
+                    else if (cnt == 0) status[my_rank] = kKept;
+                    gcnt[p] = cnt;
+                    int4 *e = reinterpret_cast<int4 *>(gedge + (size_t)p * kGraphEdges);
+                    e[0] = make_int4(le[0], le[1], le[2], le[3]);
+                    e[1] = make_int4(le[4], le[5], le[6], le[7]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // kept rows in rank order
+    const int max_out = a.max_out > 0 ? a.max_out : 0x7fffffff;
+    int nkept = 0;
+    for (int i0 = 0; i0 < K && nkept < max_out; i0 += kSegThreads) {
+        const int i = i0 + tid;
+        const bool kept = i < K && status[i] == kKept;
+        int total;
+        const int rank = tile_rank_rows(kept, s_bal, total);
+        if (kept && nkept + rank < max_out) a.kept_slot[reg + nkept + rank] = a.sslot[reg + i];
+        nkept += total;
+        __syncthreads();
+    }
+    if (nkept > max_out) nkept = max_out;
+    pairs = (unsigned int)wave_sum((int)pairs);
+    ties = (unsigned int)wave_sum((int)ties);
+    if (lane == 0 && pairs) atomicAdd(&a.seg_pairs[seg], pairs);
+    if (lane == 0 && ties) atomicAdd(&a.seg_ties[seg], ties);
+    if (tid == 0) a.seg_kept[seg] = nkept;
+}

@@ -281,11 +281,16 @@ int yp_loss_custom_reference(const float *d_pred, const float *d_true_grid, int 
  * yp_filter_boxes_reference call is launched with a start and a stop HIP event of its own
  * (hipExtLaunchKernelGGL), on the stream the call uses; at most max_calls calls are
  * recorded.  yp_profile_stop waits for the recorded events and returns the average
- * execution time in milliseconds of the front (decode + filter + compaction) kernel, the
- * segment NMS kernel and the final gather kernel.  Not thread-safe; intended for a single
+ * execution time in milliseconds per call of the front (decode + filter + compaction) kernel,
+ * the NMS stage and the final gather kernel.  Not thread-safe; intended for a single
  * measuring thread. */
 int yp_profile_start(int max_calls);
 int yp_profile_stop(double *front_ms, double *nms_ms, double *gather_ms, int *calls);
+/* The same with the kernels of the NMS stage apart: ms[5] = average milliseconds per recorded
+ * call of the front kernel, the segment NMS kernel, the row gather, and the two kernels that
+ * finish large segments (pair tests over the spatial index; resolution of the keep set) --
+ * yp_profile_stop adds the last two to nms_ms. */
+int yp_profile_stop_ex(double *ms, int *calls);
 
 #ifdef __cplusplus
 }
