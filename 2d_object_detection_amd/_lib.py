@@ -19,6 +19,7 @@ YP_MAX_SETS = 8
 YP_STATS_PLANES = 4   # survivors, kept, IoU pairs evaluated, IoU-at-threshold ties
 YP_MODE_YOLOV3 = 0
 YP_MODE_REFERENCE = 1
+YP_FLAG_DENSE_NMS = 1
 
 # every symbol include/yolopost.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
@@ -59,7 +60,7 @@ class YpParams(ctypes.Structure):
         ("im_h", ctypes.c_float),
         ("im_w", ctypes.c_float),
         ("batch_offset", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
     ]
 
 

@@ -54,6 +54,9 @@ constexpr int kSmallBytes = 32 * (kSmallCap + 8) + 16 * 32;   // + 32 boxes the 
 #ifndef YP_GRAPH_MIN
 #define YP_GRAPH_MIN 768
 #endif
+#ifndef YP_GRAPH_WGS
+#define YP_GRAPH_WGS 1280
+#endif
 struct GraphSeg;
 
 // ------------------------------------------------------------------------ device structs
@@ -95,7 +98,7 @@ struct CandBuf {
     int tpi;  // tiles per image
     int ts;   // slots per tile
     int *ctrl;  // launch control words, cleared by the front kernel: [0] some segment took the
-                // graph path, [1] bin tables handed out
+                // graph path, [1] bin tables handed out, [2] batches of 64 boxes in those segments
 };
 
 // The first thread of a front kernel clears the control words of the launch (the kernels that
@@ -105,6 +108,7 @@ __device__ __forceinline__ void clear_ctrl(const CandBuf &cb)
     if (cb.ctrl && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
         cb.ctrl[0] = 0;
         cb.ctrl[1] = 0;
+        cb.ctrl[2] = 0;
     }
 }
 
@@ -1745,6 +1749,7 @@ void k_segment_nms(SegArgs s)
                     GraphSeg g;
                     g.K = K;
                     g.table = atomicAdd(&s.ctrl[1], 1);
+                    atomicAdd(&s.ctrl[2], (K + 63) >> 6);
                     g.e_min = e_min;
                     int d = 0;
                     while ((float)(1 << d) < 1.001f / s.thr) ++d;
@@ -2226,8 +2231,10 @@ bool params_ok(const YpParams *p, int mode)
     if (!p || p->mode != mode || p->batch <= 0 || p->batch > 65535) return false;
     if (p->num_classes <= 0 || p->num_classes > 4096) return false;
     if (!(p->nms_thr == p->nms_thr) || !(p->conf_thr == p->conf_thr)) return false;
-#ifndef YP_DIAG
-    if (p->reserved != 0) return false;   // (diagnostic builds read a stage mask here)
+#ifdef YP_DIAG
+    if ((p->flags & ~(YP_FLAG_DENSE_NMS | 0x700)) != 0) return false;   // bits 8-10: stage mask
+#else
+    if ((p->flags & ~YP_FLAG_DENSE_NMS) != 0) return false;
 #endif
     return true;
 }
@@ -2397,16 +2404,20 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
 {
     const int n_seg = n_sets * p->batch * p->num_classes;
 #ifdef YP_DIAG
-    const int stages = p->reserved ? p->reserved : 7;   // diagnostic build: run a subset of the stages
+    const int stages = (p->flags >> 8) & 7 ? (p->flags >> 8) & 7 : 7;   // diagnostic build: a subset of the stages
 #else
     const int stages = 7;
 #endif
     SegArgs s = make_seg_args(w, p, spi, tpi, ts, 1);
     s.B = n_sets * p->batch;
     s.max_out = p->max_out;
+    // Large segments go to the graph kernels only when the caller asks for it: the two extra
+    // launches cost a few microseconds per call even when no segment is large.
+    const bool dense = (p->flags & YP_FLAG_DENSE_NMS) != 0 && w.gseg != nullptr && spi > kGraphMin;
+    if (!dense) s.gseg = nullptr;
     if (stages & 2)
         YP_LAUNCH(1, k_segment_nms<YP_MODE_YOLOV3>, dim3(n_seg), dim3(kSegThreads), 0, st, s);
-    if ((stages & 2) && w.gseg && spi > kGraphMin) {
+    if ((stages & 2) && dense) {
         // segments the NMS kernel handed to the graph path (none: both kernels leave at once)
         GraphArgs ga = {};
         ga.per_class = 1;
@@ -2434,7 +2445,7 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
         long long n_tables = slots_all / kGraphMin + 1;
         n_tables = n_tables < n_seg ? n_tables : n_seg;
         long long n_wg = slots_all / 64 / 2 + 1;
-        n_wg = n_wg > 1280 ? 1280 : n_wg;
+        n_wg = n_wg > YP_GRAPH_WGS ? YP_GRAPH_WGS : n_wg;
         YP_LAUNCH(3, k_graph_pairs<YP_MODE_YOLOV3>, dim3((unsigned)n_wg), dim3(kGraphThreads), 0, st, ga,
                   w.ctrl);
         YP_LAUNCH(4, k_graph_resolve<YP_MODE_YOLOV3>, dim3((unsigned)n_tables), dim3(kSegThreads), 0, st, ga,
@@ -2603,7 +2614,7 @@ static int detect_v3_sets(const YpHead *heads, int n_heads, int n_sets, const Yp
     bool all_three = true;
     for (int i = 0; i < n_heads; ++i) all_three = all_three && heads[i].num_anchors == 3;
 #ifdef YP_DIAG
-    const bool run_front = !params->reserved || (params->reserved & 1);
+    const bool run_front = !((params->flags >> 8) & 7) || ((params->flags >> 8) & 1);
 #else
     const bool run_front = true;
 #endif

@@ -36,7 +36,16 @@ constexpr int kGraphMin = YP_GRAPH_MIN;   // segments with more candidates take 
 constexpr int kGraphBins = 4096;          // bins of a segment's index (all classes together)
 constexpr int kGraphClasses = 8;          // size classes (powers of two of max(width, height))
 constexpr int kGraphEdges = 8;            // recorded suppressors per column (the earliest + 7)
-constexpr int kGraphRowTile = 256;        // rows a wave stages in LDS per pass
+#ifndef YP_GRAPH_TILE
+#define YP_GRAPH_TILE 256
+#endif
+#ifndef YP_GRAPH_WPE
+#define YP_GRAPH_WPE 3
+#endif
+#ifndef YP_GRAPH_WAVEMODE
+#define YP_GRAPH_WAVEMODE 0
+#endif
+constexpr int kGraphRowTile = YP_GRAPH_TILE;   // candidate rows a wave fetches per pass
 constexpr int kGraphThreads = 256;        // k_graph_pairs workgroup
 constexpr int kGraphWaves = kGraphThreads / 64;
 constexpr int kGraphRanges = 64;          // bin ranges a wave looks up per pass
@@ -262,38 +271,46 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
     };
 
     // ranges = (class, cell row) pairs in reach, each a run of consecutive cells = one contiguous
-    // run of index positions; numbered class-major and handed to the lanes 64 at a time
-    int n_ranges = 0;
-    for (int c = c_lo; c <= c_hi; ++c) {
-        if (gs.nx[c] <= 0) continue;
-        const float reach = gs.half[c] + gs.margin;
-        const int iy0 = graph_cell(bylo - reach, gs.y0, gs.invy[c], gs.ny[c]);
-        const int iy1 = graph_cell(byhi + reach, gs.y0, gs.invy[c], gs.ny[c]);
-        n_ranges += iy1 - iy0 + 1;
+    // run of index positions; numbered class-major and handed to the lanes 64 at a time.  Lane
+    // c < kGraphClasses works out class c's window once; the lanes then pick theirs from it.
+    int w_n = 0, w_iy0 = 0, w_ix0 = 0, w_ix1 = 0, w_nx = 1, w_base = 0;
+    if (lane >= c_lo && lane <= c_hi && gs.nx[lane] > 0) {
+        const float reach = gs.half[lane] + gs.margin;
+        w_nx = gs.nx[lane];
+        w_base = gs.base[lane];
+        w_iy0 = graph_cell(bylo - reach, gs.y0, gs.invy[lane], gs.ny[lane]);
+        w_n = graph_cell(byhi + reach, gs.y0, gs.invy[lane], gs.ny[lane]) - w_iy0 + 1;
+        w_ix0 = graph_cell(bxlo - reach, gs.x0, gs.invx[lane], w_nx);
+        w_ix1 = graph_cell(bxhi + reach, gs.x0, gs.invx[lane], w_nx);
     }
+    const int w_incl = wave_inclusive_scan(w_n, lane);
+    const int n_ranges = __builtin_amdgcn_readlane(w_incl, kGraphClasses - 1);
     int tile_no = 0;     // candidate tiles of the batch, numbered over all passes
     for (int g0 = 0; g0 < n_ranges; g0 += kGraphRanges) {
         // lane l: range g0 + l
         int beg = 0, len = 0;
         {
-            int want = g0 + lane, seen = 0;
-            for (int c = c_lo; c <= c_hi; ++c) {
-                if (gs.nx[c] <= 0) continue;
-                const float reach = gs.half[c] + gs.margin;
-                const int iy0 = graph_cell(bylo - reach, gs.y0, gs.invy[c], gs.ny[c]);
-                const int iy1 = graph_cell(byhi + reach, gs.y0, gs.invy[c], gs.ny[c]);
-                const int n = iy1 - iy0 + 1;
-                if (want >= seen && want < seen + n) {
-                    const int iy = iy0 + (want - seen);
-                    const int ix0 = graph_cell(bxlo - reach, gs.x0, gs.invx[c], gs.nx[c]);
-                    const int ix1 = graph_cell(bxhi + reach, gs.x0, gs.invx[c], gs.nx[c]);
-                    const int b0 = gs.base[c] + iy * gs.nx[c];
-                    const int ca = (iy & 1) ? gs.nx[c] - 1 - ix1 : ix0;     // (odd rows run backwards)
-                    const int cb = (iy & 1) ? gs.nx[c] - 1 - ix0 : ix1;
-                    beg = off[b0 + ca];
-                    len = off[b0 + cb + 1] - beg;
+            const int want = g0 + lane;
+            int iy = 0, ix0 = 0, ix1 = 0, nx = 1, base = 0;
+            bool found = false;
+#pragma unroll
+            for (int c = 0; c < kGraphClasses; ++c) {
+                const int hi = __builtin_amdgcn_readlane(w_incl, c), n = __builtin_amdgcn_readlane(w_n, c);
+                if (want >= hi - n && want < hi) {
+                    found = true;
+                    iy = __builtin_amdgcn_readlane(w_iy0, c) + (want - (hi - n));
+                    ix0 = __builtin_amdgcn_readlane(w_ix0, c);
+                    ix1 = __builtin_amdgcn_readlane(w_ix1, c);
+                    nx = __builtin_amdgcn_readlane(w_nx, c);
+                    base = __builtin_amdgcn_readlane(w_base, c);
                 }
-                seen += n;
+            }
+            if (found) {
+                const int b0 = base + iy * nx;
+                const int ca = (iy & 1) ? nx - 1 - ix1 : ix0;     // (odd rows run backwards)
+                const int cb = (iy & 1) ? nx - 1 - ix0 : ix1;
+                beg = off[b0 + ca];
+                len = off[b0 + cb + 1] - beg;
             }
         }
         const int incl = wave_inclusive_scan(len, lane);
@@ -362,12 +379,14 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
 // the batches blockIdx.x, blockIdx.x + gridDim.x, ... of each (rotated from segment to segment
 // so that short segments do not all land on the first workgroups).
 template <int MODE>
-__global__ __launch_bounds__(kGraphThreads) void k_graph_pairs(GraphArgs a, const int *ctrl)
+__global__ __launch_bounds__(kGraphThreads) __attribute__((amdgpu_waves_per_eu(YP_GRAPH_WPE)))
+void k_graph_pairs(GraphArgs a, const int *ctrl)
 {
     __shared__ GraphWaveShared s_ws[kGraphWaves];
     __shared__ GraphSeg s_gs;
     const int n_graph = ctrl[1];                    // graph segments of this launch
     if (n_graph == 0) return;
+    const bool wave_mode = YP_GRAPH_WAVEMODE && ctrl[2] >= 2 * (int)gridDim.x;   // batches of all of them
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const YpThr thr = yp_make_thr(a.thr);
     GraphWaveShared &ws = s_ws[wave];
@@ -389,15 +408,20 @@ __global__ __launch_bounds__(kGraphThreads) void k_graph_pairs(GraphArgs a, cons
         unsigned int pairs = 0, ties = 0;
         const int n_batches = (K + 63) >> 6;
         const int start = (int)((blockIdx.x + (unsigned)t * 37u) % gridDim.x);
-        for (int batch = start; batch < n_batches; batch += gridDim.x) {
+        // With batches to spare every wave takes a batch of its own (the window set-up is then
+        // paid once per batch); with few of them the waves of a workgroup share one batch's tiles.
+        const int per_wg = wave_mode ? kGraphWaves : 1;
+        for (int grp = start; grp * per_wg < n_batches; grp += gridDim.x) {
+            const int batch = wave_mode ? grp * kGraphWaves + wave : grp;
+            if (batch >= n_batches) continue;
             const int p = batch * 64 + lane;
             const bool live = p < K;
             const float4 cj = xraw[live ? p : K - 1];
             const int my_rank = live ? xidx[p] : -1;
             bool kept_hit;
             graph_walk<MODE, false>(s_gs, off, xraw, xidx, nullptr, a.gcnt + reg, a.gedge + reg * kGraphEdges,
-                                    cj, my_rank, p, live, thr, ws, wave, kGraphWaves, nullptr, pairs, ties,
-                                    kept_hit);
+                                    cj, my_rank, p, live, thr, ws, wave_mode ? 0 : wave,
+                                    wave_mode ? 1 : kGraphWaves, nullptr, pairs, ties, kept_hit);
         }
         if (lane == 0 && pairs) atomicAdd(&a.seg_pairs[seg], pairs);
         if (lane == 0 && ties) atomicAdd(&a.seg_ties[seg], ties);

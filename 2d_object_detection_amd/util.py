@@ -78,7 +78,17 @@ def predict_transform_heads(heads, inp_dim, anchors_per_head, num_classes):
     return rows
 
 
-def _v3_params(batch, num_classes, confidence, nms_conf, batch_offset=0):
+def _dense_nms(dense_nms, confidence, rows_per_image, num_classes):
+    """Whether to ask for the multi-workgroup path for large NMS segments (YP_FLAG_DENSE_NMS):
+    an explicit True/False wins; None decides from the configuration -- a confidence threshold
+    below 0.1 on more than 2048 anchors per class lets thousands of candidates through per
+    (image, class).  Results do not depend on it, only the time does."""
+    if dense_nms is None:
+        return confidence < 0.1 and rows_per_image > 2048 * max(int(num_classes), 1)
+    return bool(dense_nms)
+
+
+def _v3_params(batch, num_classes, confidence, nms_conf, batch_offset=0, dense=False):
     p = _lib.YpParams()
     p.mode = _lib.YP_MODE_YOLOV3
     p.batch = int(batch)
@@ -87,11 +97,12 @@ def _v3_params(batch, num_classes, confidence, nms_conf, batch_offset=0):
     p.conf_thr = float(confidence)
     p.nms_thr = float(nms_conf)
     p.batch_offset = int(batch_offset)
+    p.flags = _lib.YP_FLAG_DENSE_NMS if dense else 0
     return p
 
 
 def write_results_device(prediction, confidence, num_classes, nms_conf=0.4, out_cap=None,
-                         want_stats=False):
+                         want_stats=False, dense_nms=None):
     """write_results without the host synchronisation: returns (rows (cap, 8), count (1,)
     int32, stats or None), all on the device; rows[:count] are the detections."""
     pred = _lib.as_f32(prediction, "prediction")
@@ -107,7 +118,8 @@ def write_results_device(prediction, confidence, num_classes, nms_conf=0.4, out_
     if B == 0 or N == 0:
         return out, count, stats
     L = _lib.load()
-    p = _v3_params(B, num_classes, confidence, nms_conf)
+    p = _v3_params(B, num_classes, confidence, nms_conf,
+                   dense=_dense_nms(dense_nms, confidence, N, num_classes))
     ws = _lib.workspace(L.yp_rows_workspace_bytes(B, N, num_classes), dev)
     with _lib.on_device(dev):
         rc = L.yp_write_results(pred.data_ptr(), N, ctypes.byref(p), out.data_ptr(), cap,
@@ -117,11 +129,12 @@ def write_results_device(prediction, confidence, num_classes, nms_conf=0.4, out_
     return out, count, stats
 
 
-def write_results(prediction, confidence, num_classes, nms_conf=0.4):
+def write_results(prediction, confidence, num_classes, nms_conf=0.4, dense_nms=None):
     """Decoded rows (B, N, 5+C) -> detections (D, 8)
     [image, x1, y1, x2, y2, objectness, class score, class id], ordered by image, class id,
     objectness descending; the int 0 when nothing survives (as the tutorial returns)."""
-    out, count, _ = write_results_device(prediction, confidence, num_classes, nms_conf)
+    out, count, _ = write_results_device(prediction, confidence, num_classes, nms_conf,
+                                         dense_nms=dense_nms)
     d = int(count.item())
     if d == 0:
         return 0
@@ -158,7 +171,7 @@ class YoloV3Post:
 
     def __init__(self, batch, inp_dim, num_classes=5, confidence=0.5, nms_conf=0.4,
                  anchors=YOLOV3_ANCHORS, strides=(32, 16, 8), device=None, out_cap=None,
-                 batch_offset=0, out=None):
+                 batch_offset=0, out=None, dense_nms=None):
         self.device = torch.device(device if device is not None
                                    else "cuda:%d" % torch.cuda.current_device())
         if self.device.type != "cuda":
@@ -170,7 +183,9 @@ class YoloV3Post:
         in_h, in_w = _dims(inp_dim)
         self.grids = [(in_h // s, in_w // s) for s in self.strides]
         self.rows_per_image = sum(gh * gw * len(a) for (gh, gw), a in zip(self.grids, anchors))
-        self.params = _v3_params(batch, num_classes, confidence, nms_conf, batch_offset)
+        self.dense_nms = _dense_nms(dense_nms, confidence, self.rows_per_image, num_classes)
+        self.params = _v3_params(batch, num_classes, confidence, nms_conf, batch_offset,
+                                 dense=self.dense_nms)
         self._lib = _lib.load()
         shape_only = (_lib.YpHead * len(self.grids))(*[
             _lib.make_head(None, gh, gw, _scaled_anchors(a, in_w // gw, in_h // gh),
@@ -266,14 +281,14 @@ class YoloV3PostMulti:
 
     def __init__(self, n_sets, batch, inp_dim, num_classes=5, confidence=0.5, nms_conf=0.4,
                  anchors=YOLOV3_ANCHORS, strides=(32, 16, 8), device=None, out_cap=None,
-                 batch_offset=0, out=None):
+                 batch_offset=0, out=None, dense_nms=None):
         if not 1 <= int(n_sets) <= _lib.YP_MAX_SETS:
             raise ValueError("1..%d sets per call" % _lib.YP_MAX_SETS)
         self.n_sets = int(n_sets)
         # geometry, validation and parameters are those of a single-set engine; its own
         # buffers are sized for one image and unused
         self._one = YoloV3Post(batch, inp_dim, num_classes, confidence, nms_conf, anchors, strides,
-                               device, out_cap=2, batch_offset=batch_offset)
+                               device, out_cap=2, batch_offset=batch_offset, dense_nms=dense_nms)
         o = self._one
         self.device, self.batch, self.num_classes = o.device, o.batch, o.num_classes
         self.grids, self.rows_per_image, self.params = o.grids, o.rows_per_image, o.params

@@ -7,10 +7,13 @@ One "step" = one pass of the fused path over one batch of synthetic raw detectio
 are already resident in HBM.  At N=1 the default workload is BASELINE.json's configs[1]: batch
 64 at 416x416, three YOLOv3 heads x 3 anchors, 5 classes, conf 0.5 / NMS 0.4.
 
-How the steps are issued.  Consecutive batches are independent, so S of them (default 4) go to
-the GPU together as ONE launch per stage (yp_detect_yolov3_multi), alternating between F
-engines on F HIP streams (default 2) so that the HBM-bound front kernel of one launch overlaps
-the issue-bound NMS kernel of the other.  K steps are ceil(K/S) launches.
+How the steps are issued.  Consecutive batches are independent, so S of them (default 8) go to
+the GPU together as ONE launch per stage (yp_detect_yolov3_multi), on F engines / HIP streams
+(default: 1 on one GPU, so that every kernel has the GPU to itself and its HIP-event time is
+what a profiler sees; 2 with N > 1, where the second stream hides the exchange).  K steps are
+ceil(K/S) launches.  (--sets-per-launch 4 --in-flight 2 overlaps the HBM-bound front kernel of
+one launch with the issue-bound NMS kernel of the other: about 15 % more images/s on long runs,
+with the front kernel's own duration stretched by what it shares the GPU with.)
 
 What the steps read.  The timed loop cycles through R distinct input sets with R x bytes per
 batch >= 512 MiB (20 sets at cfg2), twice the 256 MiB Infinity Cache, so every batch is read
@@ -198,9 +201,10 @@ def main():
                          "print one JSON line per kernel")
     ap.add_argument("--sets-per-launch", type=int, default=0,
                     help="independent batches handed to the GPU as one launch per stage (1..8); "
-                         "0 = 4, or 1 for batches above 64 MB")
-    ap.add_argument("--in-flight", type=int, default=2,
-                    help="engines x HIP streams the launches alternate between")
+                         "0 = 8, or 1 for batches above 64 MB")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="engines x HIP streams the launches alternate between; 0 = 1 on one GPU, "
+                         "2 with N > 1 (the same on every rank)")
     ap.add_argument("--cycle-mib", type=int, default=CYCLE_BYTES >> 20,
                     help="distinct input bytes the timed loop cycles through")
     ap.add_argument("--no-exchange", action="store_true",
@@ -244,9 +248,9 @@ def main():
     rows_per_image = syn.anchors_per_image(inp_dim if isinstance(inp_dim, int) else tuple(inp_dim))
     batch_bytes = sum(h.numel() * 4 for h in base)
     K, W = args.steps, args.warmup
-    S = args.sets_per_launch or (4 if batch_bytes <= (64 << 20) else 1)
+    S = args.sets_per_launch or (8 if batch_bytes <= (64 << 20) else 1)
     S = max(1, min(S, _lib.YP_MAX_SETS, K))
-    F = max(1, args.in_flight)       # the same on every rank: the ranks issue identical sequences
+    F = args.in_flight if args.in_flight > 0 else (2 if multi else 1)   # the same on every rank
     # R distinct input sets, a multiple of S so that the launches see a handful of fixed groups
     R = max(S, -(-(args.cycle_mib << 20) // batch_bytes))
     # (at most 48 launch groups, which the engines' descriptor cache holds: tiny batches such as
@@ -350,7 +354,7 @@ def main():
 
     # ---- per-kernel execution times: each launch carries its own start/stop HIP events on the
     # launch stream (separate passes so the event bookkeeping does not perturb the loop above)
-    plan = launch_plan(max(K, 4 * S * F))
+    plan = launch_plan(max(K, 16 * S * F))
     nprof = min(len(plan), 64)
     plan = plan[:nprof]
     # (a) in the regime of the timed region: F streams, inputs cycling through HBM
@@ -392,14 +396,19 @@ def main():
         alg_batch = 40.0 * n_anchors + 28.0 * total_surv + 4.0 * tiles
         alg_bytes = S * alg_batch
         achieved = alg_bytes / (front_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_note = None, None
         tfile = os.path.join(ROOT, "profiles", "r02_front_kernel_traffic.json")
         if os.path.exists(tfile) and not args.clustered:
-            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this
-            # same command, collected offline and committed; see the file for the correction
+            # HBM bytes from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this benchmark,
+            # collected offline and committed (see the file for the correction).  The sets of a
+            # launch are processed by disjoint workgroups (blockIdx.z), so the per-batch figure
+            # carries over to another number of batches per launch.
             t = json.load(open(tfile)).get(args.config, {})
-            if t.get("sets_per_launch") == S:
-                traffic = t.get("traffic_bytes")
+            if t.get("traffic_bytes") and t.get("sets_per_launch"):
+                traffic = int(t["traffic_bytes"] / t["sets_per_launch"] * S)
+                traffic_note = ("%d B per batch measured at %d batches per launch (%s), x %d"
+                                % (t["traffic_bytes"] // t["sets_per_launch"], t["sets_per_launch"],
+                                   os.path.basename(tfile), S))
         frac = lambda ms: round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         out = {
             "metric": "decode+NMS images/sec",
@@ -438,6 +447,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_front_heads_v3_wave (decode+filter+compaction)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "traffic_note": traffic_note,
                          "algorithmic_bytes": int(alg_bytes),
                          "algorithmic_bytes_per_batch": int(alg_batch),
                          "batches_per_launch": S,

@@ -48,6 +48,16 @@ extern "C" {
 
 enum { YP_MODE_YOLOV3 = 0, YP_MODE_REFERENCE = 1 };
 
+/* YpParams.flags.
+ * YP_FLAG_DENSE_NMS (YP_MODE_YOLOV3 entries): expect (image, class) segments with thousands of
+ * candidates -- low confidence thresholds, large inputs.  Segments above 768 candidates are then
+ * finished by two extra kernels that spread one segment over many workgroups (pair tests over a
+ * spatial index, then a fixed-point resolution of the keep set) instead of by their one
+ * workgroup; results are bit-identical either way.  Without the flag nothing is launched for it.
+ * Needs nms_thr in [0.05, 1] and boxes of positive size; segments that do not qualify fall back
+ * to the one-workgroup path by themselves. */
+enum { YP_FLAG_DENSE_NMS = 1 };
+
 enum {
     YP_OK = 0,
     YP_ERR_ARG = -1,        /* null pointer, non-positive size, value out of range */
@@ -88,7 +98,7 @@ typedef struct YpParams {
     float im_h;           /* YP_MODE_REFERENCE: params.im_height */
     float im_w;           /* YP_MODE_REFERENCE: params.im_width */
     int32_t batch_offset; /* YP_MODE_YOLOV3: added to the image index written in column 0 */
-    int32_t reserved;     /* must be 0 (anything else is YP_ERR_ARG) */
+    int32_t flags;        /* YP_FLAG_* bits; any other bit set is YP_ERR_ARG */
 } YpParams;
 
 int yp_version(void);
@@ -155,7 +165,7 @@ int yp_detect_yolov3_multi(const YpHead *heads, int n_heads, int n_sets, const Y
  * static device array inside the library (YP_NOALLOC_SCRATCH_BYTES = 16 MiB per GPU the
  * library runs on, held until the process ends); the call allocates and frees nothing.
  * Problems whose workspace (yp_detect_yolov3_workspace_bytes) exceeds that size return
- * YP_ERR_SCRATCH and launch nothing: 16 MiB covers e.g. 16 images at 416x416 or one image at
+ * YP_ERR_SCRATCH and launch nothing: 16 MiB covers e.g. 12 images at 416x416 or one image at
  * 1920x1280 with three anchors per head.  All calls on one GPU share that GPU's array: calls
  * that overlap on one GPU (different streams or threads) race; order them on one stream.
  * The array's device address is looked up on the first call on each device;

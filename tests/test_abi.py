@@ -66,11 +66,13 @@ def test_bad_arguments_are_rejected_without_a_gpu(pkg):
     assert lib.yp_bbox_iou(None, fake, 3, 4, fake, None) == -1
     assert lib.yp_bbox_iou(fake, fake, 3, 2, fake, None) == -1
     assert lib.yp_write_results(None, 10, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
-    # the reserved field must be zero (it is no stage mask in the shipping library)
-    p.batch, p.reserved = 1, 2
+    # unknown flag bits are refused (the field is no stage mask in the shipping library)
+    p.batch, p.flags = 1, 2
     assert lib.yp_detect_yolov3(heads, 1, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
     assert lib.yp_write_results(fake, 10, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
-    p.reserved = 0
+    p.flags = 0x100
+    assert lib.yp_detect_yolov3(heads, 1, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
+    p.flags = 0
     # reference-mode entries pad their outputs to max_out rows per image: 1 <= max_out <= 2^20
     r = L.YpParams()
     r.mode, r.batch, r.num_classes, r.conf_thr, r.nms_thr = L.YP_MODE_REFERENCE, 1, 5, 0.6, 0.5

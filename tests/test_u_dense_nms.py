@@ -1,0 +1,69 @@
+"""YP_FLAG_DENSE_NMS: large (image, class) segments finished by the graph kernels (a spatial
+index, pair tests spread over many workgroups, fixed-point resolution of the keep set) instead of
+by the segment's one workgroup.  The flag changes how the keep set is computed, never what it is:
+every output bit must equal the oracle's and the other path's."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from test_gpu_parity import big_segment_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,seed,nms,degenerate,offset", [
+    (1500, 1, 0.4, False, 0.0),
+    (3000, 2, 0.45, False, 0.0),
+    (4700, 8, 0.4, False, 0.0),
+    (9000, 9, 0.3, False, 0.0),       # several tiles of candidate rows per batch of columns
+    (1400, 3, 0.4, True, 0.0),        # boxes without a positive size: the segment declines the path
+    (1300, 4, 0.0, False, 0.0),       # thresholds outside [0.05, 1]: likewise
+    (1300, 5, 1.0, False, 0.0),       # threshold 1: only identical boxes suppress
+    (1600, 6, 0.4, False, 3.0e7),     # coordinates where a float's spacing exceeds 2 px
+    (1000, 7, 0.05, False, 0.0),      # just above the path's minimum size, lowest threshold it takes
+])
+def test_dense_nms_rows_match_oracle_and_default_path(pkg, dev, n, seed, nms, degenerate, offset):
+    util = pkg.util
+    rows, C = big_segment_rows(n, seed, degenerate=degenerate, offset=offset)
+    want, surv, _ = oracle.n_write_results(rows, 0.5, C, nms)
+    assert surv.max() > 768
+    d_rows = torch.from_numpy(rows).to(dev)
+    for dense in (True, False):
+        got = util.write_results(d_rows, 0.5, C, nms, dense_nms=dense)
+        got = np.zeros((0, 8), np.float32) if isinstance(got, int) else got.cpu().numpy()
+        assert got.shape == want.shape, (dense, got.shape, want.shape)
+        assert np.array_equal(got, want), dense
+    # statistics: survivors and kept rows per segment agree between the two paths
+    _, _, st_d = util.write_results_device(d_rows, 0.5, C, nms, want_stats=True, dense_nms=True)
+    _, _, st_o = util.write_results_device(d_rows, 0.5, C, nms, want_stats=True, dense_nms=False)
+    assert np.array_equal(st_d[:2].cpu().numpy(), st_o[:2].cpu().numpy())
+
+
+@pytest.mark.parametrize("inp_dim,B,conf,clustered,seed", [
+    (416, 2, 0.001, False, 4),              # near-all survive: ~2000 candidates per segment
+    ((320, 480), 2, 0.01, True, 12),
+    ((1280, 1920), 1, 0.5, True, 13),       # clustered scene at full size: dense overlaps
+    ((1280, 1920), 1, 0.001, False, 14),    # ~30k candidates per segment
+])
+def test_dense_nms_from_heads_matches_oracle(pkg, dev, inp_dim, B, conf, clustered, seed):
+    syn, util = pkg.synthetic, pkg.util
+    heads = syn.make_heads(B, inp_dim, 5, seed=seed, clustered=clustered)
+    want, surv, _ = oracle.n_detect([h.numpy() for h in heads], inp_dim, syn.YOLOV3_ANCHORS, 5, conf, 0.4)
+    dheads = [h.to(dev) for h in heads]
+    for dense in (True, False):
+        eng = util.YoloV3Post(B, inp_dim, 5, conf, 0.4, device=dev, dense_nms=dense)
+        got = eng.detect(dheads).cpu().numpy()
+        assert got.shape == want.shape, (dense, got.shape, want.shape)
+        assert np.array_equal(got, want), dense
+        s_surv, s_kept, _ = eng.segment_stats()
+        assert np.array_equal(s_surv.sum(1), surv) and int(s_kept.sum()) == want.shape[0]
+        assert np.array_equal(eng.detect(dheads).cpu().numpy(), got)      # again, same buffers
+
+
+def test_dense_flag_is_chosen_from_the_configuration(pkg, dev):
+    util = pkg.util
+    assert util.YoloV3Post(1, 416, 5, 0.001, 0.4, device=dev).dense_nms is True
+    assert util.YoloV3Post(1, 416, 5, 0.5, 0.4, device=dev).dense_nms is False
+    assert util.YoloV3Post(1, 96, 5, 0.001, 0.4, device=dev).dense_nms is False       # few anchors
+    assert util.YoloV3Post(1, 416, 5, 0.5, 0.4, device=dev, dense_nms=True).dense_nms is True
