@@ -373,12 +373,14 @@ def main():
         engines[0].run([input_sets[(i * S + t) % R] for t in range(S)])
     alone["front"], alone["segment_nms"], alone["gather"], _ = _lib.profile_stop()
     torch.cuda.synchronize()
-    # (c) the same S input sets every launch: they stay in the Infinity Cache
+    # (c) the same input sets every launch, at most 4 distinct ones (109 MB at cfg2): they stay
+    # in the Infinity Cache
+    cached_sets = [input_sets[t % min(S, 4)] for t in range(S)]
     for i in range(8):
-        engines[0].run(input_sets[:S])
+        engines[0].run(cached_sets)
     _lib.profile_start(nprof)
     for i in range(nprof):
-        engines[0].run(input_sets[:S])
+        engines[0].run(cached_sets)
     front_cached_ms, _, _, _ = _lib.profile_stop()
     torch.cuda.synchronize()
 
