@@ -149,3 +149,35 @@ def test_params_mirror_reference_names(pkg):
     assert tuple(a.shape) == (5, 2) and a.dtype == torch.float32
     assert a.numpy().shape == (5, 2)
     assert pkg.DetectNet.get_new_dim(416, 3, 1, 1) == 416
+
+
+def test_abi_validation_layer_under_host_sanitizers():
+    """The argument validation and workspace layout code of the C ABI, compiled for the host with
+    AddressSanitizer + UndefinedBehaviorSanitizer (tests/abi_sanitized.cpp linked against the
+    library's own sources) and run without a GPU: every call is rejected before a launch, and the
+    sanitizers must stay silent."""
+    import shutil
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc is not installed here")
+    csrc = os.path.join(here, "..", "2d_object_detection_amd", "csrc")
+    build = os.path.join(here, "_build")
+    os.makedirs(build, exist_ok=True)
+    exe = os.path.join(build, "abi_sanitized")
+    srcs = [os.path.join(here, "abi_sanitized.cpp")] + [os.path.join(csrc, f) for f in
+                                                         ("yolopost.hip", "gridcodec.hip", "decode_grad.hip")]
+    deps = srcs + [os.path.join(csrc, f) for f in ("yp_graph.h", "yp_math.h", "yp_tile.h")] + \
+        [os.path.join(here, "..", "include", "yolopost.h")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(f) for f in deps):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off",
+                               "-fhip-fp32-correctly-rounded-divide-sqrt",
+                               "-I" + os.path.join(here, "..", "include"), "-I" + csrc,
+                               "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined",
+                               "-Xarch_host", "-fno-sanitize-recover=undefined", "-o", exe] + srcs)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", HIP_VISIBLE_DEVICES="")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.strip().splitlines()[-1].startswith("ok "), out.stdout[-500:]
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-4000:]
