@@ -20,6 +20,7 @@ YP_STATS_PLANES = 4   # survivors, kept, IoU pairs evaluated, IoU-at-threshold t
 YP_MODE_YOLOV3 = 0
 YP_MODE_REFERENCE = 1
 YP_FLAG_DENSE_NMS = 1
+YP_FLAG_RESCALE = 2
 
 # every symbol include/yolopost.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (

@@ -167,6 +167,10 @@ struct GatherArgs {
     int n_seg, C, spi, batch_offset;
     int spset;               // segments per set (images per set x classes)
     long long set_stride;    // floats between the output rows of consecutive sets
+    // YP_FLAG_RESCALE: kept boxes leave the network-input frame for the original one
+    // (x - pad_x) / scale clamped to [0, im_w], likewise y; NMS has run on the unscaled boxes
+    int rescale;
+    float pad_x, pad_y, scale, im_w, im_h;
     const float4 *cand_box;
     const float *cand_key;
     const float *cand_aux;
@@ -2031,7 +2035,13 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_rows(GatherArgs g)
         const long long d = (long long)prefix + k;
         if (d >= g.cap) break;
         const int slot = g.kept_slot[reg + k];
-        const float4 bx = g.cand_box[ibase + slot];
+        float4 bx = g.cand_box[ibase + slot];
+        if (g.rescale) {
+            bx.x = vmin(vmax((bx.x - g.pad_x) / g.scale, 0.0f), g.im_w);
+            bx.y = vmin(vmax((bx.y - g.pad_y) / g.scale, 0.0f), g.im_h);
+            bx.z = vmin(vmax((bx.z - g.pad_x) / g.scale, 0.0f), g.im_w);
+            bx.w = vmin(vmax((bx.w - g.pad_y) / g.scale, 0.0f), g.im_h);
+        }
         float4 *o = reinterpret_cast<float4 *>(rows_out + d * 8);
         o[0] = make_float4((float)(b_in_set + g.batch_offset), bx.x, bx.y, bx.z);
         o[1] = make_float4(bx.w, g.cand_key[ibase + slot], g.cand_aux[ibase + slot], (float)c);
@@ -2232,10 +2242,16 @@ bool params_ok(const YpParams *p, int mode)
     if (p->num_classes <= 0 || p->num_classes > 4096) return false;
     if (!(p->nms_thr == p->nms_thr) || !(p->conf_thr == p->conf_thr)) return false;
 #ifdef YP_DIAG
-    if ((p->flags & ~(YP_FLAG_DENSE_NMS | 0x700)) != 0) return false;   // bits 8-10: stage mask
+    if ((p->flags & ~(YP_FLAG_DENSE_NMS | YP_FLAG_RESCALE | 0x700)) != 0) return false;   // bits 8-10: stage mask
 #else
-    if ((p->flags & ~YP_FLAG_DENSE_NMS) != 0) return false;
+    if ((p->flags & ~(YP_FLAG_DENSE_NMS | YP_FLAG_RESCALE)) != 0) return false;
 #endif
+    if (p->flags & YP_FLAG_RESCALE) {
+        // only the YOLOv3 entries that see the head geometry rescale; the frame must be a real one
+        if (mode != YP_MODE_YOLOV3 || !(p->im_h > 0.0f) || !(p->im_w > 0.0f) || !(p->im_h < 1e9f) ||
+            !(p->im_w < 1e9f))
+            return false;
+    }
     return true;
 }
 
@@ -2400,7 +2416,8 @@ inline void prof_next()
 
 // Segment NMS + final gather of the YOLOv3 path (shared by the heads and rows entries).
 int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tpi, int ts,
-              float *out_rows, long long cap, int32_t *out_count, int32_t *stats, hipStream_t st)
+              float *out_rows, long long cap, int32_t *out_count, int32_t *stats, hipStream_t st,
+              float inp_w = 0.0f, float inp_h = 0.0f)
 {
     const int n_seg = n_sets * p->batch * p->num_classes;
 #ifdef YP_DIAG
@@ -2459,6 +2476,17 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
     g.spset = p->batch * p->num_classes;
     g.set_stride = cap * 8;
     g.seg_ties = w.seg_ties;
+    if (p->flags & YP_FLAG_RESCALE) {
+        // letterbox geometry of a frame im_w x im_h resized into the inp_w x inp_h network input
+        // with its aspect ratio kept and centred: every quantity in binary32, in this order
+        const float sx = inp_w / p->im_w, sy = inp_h / p->im_h;
+        g.rescale = 1;
+        g.scale = sx < sy ? sx : sy;
+        g.pad_x = (inp_w - g.scale * p->im_w) / 2.0f;
+        g.pad_y = (inp_h - g.scale * p->im_h) / 2.0f;
+        g.im_w = p->im_w;
+        g.im_h = p->im_h;
+    }
     g.cand_box = w.cand_box;
     g.cand_key = w.cand_key;
     g.cand_aux = w.cand_aux;
@@ -2631,8 +2659,10 @@ static int detect_v3_sets(const YpHead *heads, int n_heads, int n_sets, const Yp
     else
         YP_LAUNCH(0, k_front_heads_v3<0>, grid, block, (size_t)ts * 6 * sizeof(float), st, ha, cb,
                   params->conf_thr, t_lo, t_hi);
+    // (network input size = grid x stride of the first head)
     return finish_v3(w, params, n_sets, (int)spi, ha.tpi, ts, d_out_rows, out_cap, d_out_count,
-                     d_stats, st);
+                     d_stats, st, (float)heads[0].grid_w * heads[0].stride_x,
+                     (float)heads[0].grid_h * heads[0].stride_y);
 }
 
 int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params, float *d_out_rows,
@@ -2737,6 +2767,7 @@ int yp_write_results(const float *d_rows, int rows_per_image, const YpParams *pa
     if (!params_ok(params, YP_MODE_YOLOV3) || !d_rows || !d_out_rows || !d_out_count ||
         out_cap < 0 || rows_per_image <= 0)
         return YP_ERR_ARG;
+    if (params->flags & YP_FLAG_RESCALE) return YP_ERR_ARG;   // decoded rows carry no input size
     if ((reinterpret_cast<uintptr_t>(d_out_rows) & 15) != 0) return YP_ERR_ARG;
     const int tpi = (rows_per_image + kRowTile - 1) / kRowTile;
     const long long spi = (long long)tpi * kRowTile;

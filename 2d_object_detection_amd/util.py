@@ -88,7 +88,9 @@ def _dense_nms(dense_nms, confidence, rows_per_image, num_classes):
     return bool(dense_nms)
 
 
-def _v3_params(batch, num_classes, confidence, nms_conf, batch_offset=0, dense=False):
+def _v3_params(batch, num_classes, confidence, nms_conf, batch_offset=0, dense=False, frame=None):
+    """``frame`` = (height, width) of the original images: kept boxes are mapped back from the
+    letterboxed network input to that frame (YP_FLAG_RESCALE)."""
     p = _lib.YpParams()
     p.mode = _lib.YP_MODE_YOLOV3
     p.batch = int(batch)
@@ -98,6 +100,9 @@ def _v3_params(batch, num_classes, confidence, nms_conf, batch_offset=0, dense=F
     p.nms_thr = float(nms_conf)
     p.batch_offset = int(batch_offset)
     p.flags = _lib.YP_FLAG_DENSE_NMS if dense else 0
+    if frame is not None:
+        p.flags |= _lib.YP_FLAG_RESCALE
+        p.im_h, p.im_w = float(frame[0]), float(frame[1])
     return p
 
 
@@ -167,11 +172,14 @@ class YoloV3Post:
     Buffers (workspace, output rows, count, statistics) are allocated once; ``run`` only
     enqueues three kernels on the current stream and returns device tensors, so it can sit
     in a serving loop without host synchronisation.  ``batch_offset`` is added to the image
-    index in column 0 (used when a batch is sharded over several GPUs)."""
+    index in column 0 (used when a batch is sharded over several GPUs).  ``frame`` = (height,
+    width) of the original images maps the kept boxes back from the letterboxed network input
+    to that frame, clamped to it (after NMS, as the YOLOv3 tutorial does); ``dense_nms`` see
+    ``_dense_nms``."""
 
     def __init__(self, batch, inp_dim, num_classes=5, confidence=0.5, nms_conf=0.4,
                  anchors=YOLOV3_ANCHORS, strides=(32, 16, 8), device=None, out_cap=None,
-                 batch_offset=0, out=None, dense_nms=None):
+                 batch_offset=0, out=None, dense_nms=None, frame=None):
         self.device = torch.device(device if device is not None
                                    else "cuda:%d" % torch.cuda.current_device())
         if self.device.type != "cuda":
@@ -185,7 +193,7 @@ class YoloV3Post:
         self.rows_per_image = sum(gh * gw * len(a) for (gh, gw), a in zip(self.grids, anchors))
         self.dense_nms = _dense_nms(dense_nms, confidence, self.rows_per_image, num_classes)
         self.params = _v3_params(batch, num_classes, confidence, nms_conf, batch_offset,
-                                 dense=self.dense_nms)
+                                 dense=self.dense_nms, frame=frame)
         self._lib = _lib.load()
         shape_only = (_lib.YpHead * len(self.grids))(*[
             _lib.make_head(None, gh, gw, _scaled_anchors(a, in_w // gw, in_h // gh),
@@ -281,14 +289,15 @@ class YoloV3PostMulti:
 
     def __init__(self, n_sets, batch, inp_dim, num_classes=5, confidence=0.5, nms_conf=0.4,
                  anchors=YOLOV3_ANCHORS, strides=(32, 16, 8), device=None, out_cap=None,
-                 batch_offset=0, out=None, dense_nms=None):
+                 batch_offset=0, out=None, dense_nms=None, frame=None):
         if not 1 <= int(n_sets) <= _lib.YP_MAX_SETS:
             raise ValueError("1..%d sets per call" % _lib.YP_MAX_SETS)
         self.n_sets = int(n_sets)
         # geometry, validation and parameters are those of a single-set engine; its own
         # buffers are sized for one image and unused
         self._one = YoloV3Post(batch, inp_dim, num_classes, confidence, nms_conf, anchors, strides,
-                               device, out_cap=2, batch_offset=batch_offset, dense_nms=dense_nms)
+                               device, out_cap=2, batch_offset=batch_offset, dense_nms=dense_nms,
+                               frame=frame)
         o = self._one
         self.device, self.batch, self.num_classes = o.device, o.batch, o.num_classes
         self.grids, self.rows_per_image, self.params = o.grids, o.rows_per_image, o.params

@@ -55,8 +55,18 @@ enum { YP_MODE_YOLOV3 = 0, YP_MODE_REFERENCE = 1 };
  * spatial index, then a fixed-point resolution of the keep set) instead of by their one
  * workgroup; results are bit-identical either way.  Without the flag nothing is launched for it.
  * Needs nms_thr in [0.05, 1] and boxes of positive size; segments that do not qualify fall back
- * to the one-workgroup path by themselves. */
-enum { YP_FLAG_DENSE_NMS = 1 };
+ * to the one-workgroup path by themselves.
+ *
+ * YP_FLAG_RESCALE (yp_detect_yolov3, _multi, _noalloc): the kept boxes are mapped from the
+ * network-input frame back to the original image, the step that follows write_results in the
+ * YOLOv3 tutorial and the counterpart of the reference scaling its boxes to the camera frame
+ * (detect_net.py:115-116, :133).  params->im_h / im_w give the original frame (one size for the
+ * whole batch, as params.im_height / im_width are in the reference); the input size is grid x
+ * stride of the first head.  With scale = min(in_w/im_w, in_h/im_h) and the letterbox pads
+ * pad = (in - scale*im)/2, every corner becomes clamp((v - pad)/scale, 0, im).  NMS runs BEFORE
+ * this, on the boxes in network-input pixels, as in the tutorial (in YP_MODE_REFERENCE the
+ * scaling precedes NMS, as in the reference). */
+enum { YP_FLAG_DENSE_NMS = 1, YP_FLAG_RESCALE = 2 };
 
 enum {
     YP_OK = 0,
@@ -95,8 +105,8 @@ typedef struct YpParams {
                              rows per image and require 1 <= max_out <= 2^20. */
     float conf_thr;       /* params.object_conf / `confidence` */
     float nms_thr;        /* params.nms_conf / `nms_conf` */
-    float im_h;           /* YP_MODE_REFERENCE: params.im_height */
-    float im_w;           /* YP_MODE_REFERENCE: params.im_width */
+    float im_h;           /* YP_MODE_REFERENCE: params.im_height; YP_FLAG_RESCALE: frame height */
+    float im_w;           /* YP_MODE_REFERENCE: params.im_width;  YP_FLAG_RESCALE: frame width */
     int32_t batch_offset; /* YP_MODE_YOLOV3: added to the image index written in column 0 */
     int32_t flags;        /* YP_FLAG_* bits; any other bit set is YP_ERR_ARG */
 } YpParams;

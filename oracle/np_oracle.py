@@ -259,3 +259,23 @@ def decode_true_box_grid(true_grid, anchors, im_h=1280, im_w=1920, exp=None):
     conv = np.array([W, H, W, H], f32)
     orig = np.array([im_w, im_h, im_w, im_h], f32)
     return ((out / conv) * orig).astype(f32), uniq                                   # :327-328
+
+
+def n_rescale(det, inp_dim, frame):
+    """Detections (D, 8) in network-input pixels -> the original frame, as the YOLOv3 tutorial
+    does after write_results (and as the reference scales its boxes to the camera frame,
+    detect_net.py:115-116, :133): scale = min(in_w/im_w, in_h/im_h), letterbox pads
+    (in - scale*im)/2, every corner (v - pad)/scale clamped to [0, im].  All in binary32, in
+    this order."""
+    f = np.float32
+    in_h, in_w = (inp_dim, inp_dim) if np.isscalar(inp_dim) else inp_dim
+    im_h, im_w = f(frame[0]), f(frame[1])
+    in_h, in_w = f(in_h), f(in_w)
+    sx, sy = in_w / im_w, in_h / im_h
+    scale = sx if sx < sy else sy
+    pad_x = (in_w - scale * im_w) / f(2.0)
+    pad_y = (in_h - scale * im_h) / f(2.0)
+    out = np.array(det, dtype=np.float32, copy=True)
+    for col, pad, top in ((1, pad_x, im_w), (2, pad_y, im_h), (3, pad_x, im_w), (4, pad_y, im_h)):
+        out[:, col] = np.minimum(np.maximum((out[:, col] - pad) / scale, f(0.0)), top)
+    return out

@@ -80,8 +80,17 @@ int main()
           YP_ERR_WORKSPACE);
     {
         YpParams q = p;
-        q.flags = 2;
+        q.flags = 4;                                   // unknown bit
         CHECK(yp_detect_yolov3(hs, 3, &q, ff, 10, fi, nullptr, fake, big, nullptr) == YP_ERR_ARG);
+        q.flags = YP_FLAG_RESCALE;                     // needs a frame
+        q.im_h = 0.0f; q.im_w = 1920.0f;
+        CHECK(yp_detect_yolov3(hs, 3, &q, ff, 10, fi, nullptr, fake, big, nullptr) == YP_ERR_ARG);
+        q.im_h = 1280.0f; q.im_w = __builtin_nanf("");
+        CHECK(yp_detect_yolov3(hs, 3, &q, ff, 10, fi, nullptr, fake, big, nullptr) == YP_ERR_ARG);
+        q.im_w = __builtin_inff();
+        CHECK(yp_detect_yolov3(hs, 3, &q, ff, 10, fi, nullptr, fake, big, nullptr) == YP_ERR_ARG);
+        q.im_w = 1920.0f;                              // decoded rows carry no input size
+        CHECK(yp_write_results(ff, 10, &q, ff, 10, fi, nullptr, fake, big, nullptr) == YP_ERR_ARG);
         q = p; q.mode = YP_MODE_REFERENCE;
         CHECK(yp_detect_yolov3(hs, 3, &q, ff, 10, fi, nullptr, fake, big, nullptr) == YP_ERR_ARG);
         q = p; q.batch = 0;

@@ -67,9 +67,15 @@ def test_bad_arguments_are_rejected_without_a_gpu(pkg):
     assert lib.yp_bbox_iou(fake, fake, 3, 2, fake, None) == -1
     assert lib.yp_write_results(None, 10, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
     # unknown flag bits are refused (the field is no stage mask in the shipping library)
-    p.batch, p.flags = 1, 2
+    p.batch, p.flags = 1, 4
     assert lib.yp_detect_yolov3(heads, 1, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
     assert lib.yp_write_results(fake, 10, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
+    # the rescale flag needs a frame, and the head geometry (not offered on decoded rows)
+    p.flags = L.YP_FLAG_RESCALE
+    assert lib.yp_detect_yolov3(heads, 1, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
+    p.im_h, p.im_w = 1280.0, 1920.0
+    assert lib.yp_write_results(fake, 10, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
+    p.im_h = p.im_w = 0.0
     p.flags = 0x100
     assert lib.yp_detect_yolov3(heads, 1, ctypes.byref(p), fake, 10, fake, None, fake, 1 << 30, None) == -1
     p.flags = 0
