@@ -21,6 +21,8 @@ YP_MODE_YOLOV3 = 0
 YP_MODE_REFERENCE = 1
 YP_FLAG_DENSE_NMS = 1
 YP_FLAG_RESCALE = 2
+YP_MATCH_PLANES = 5
+YP_MATCH_NONE, YP_MATCH_DUPLICATE, YP_MATCH_OTHER_CLASS = -1, -2, -3
 
 # every symbol include/yolopost.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
@@ -34,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "yp_encode_true_box_grid", "yp_true_box_grid_workspace_bytes", "yp_decode_true_box_grid",
     "yp_predict_transform_reference_backward",
     "yp_loss_custom_reference_workspace_bytes", "yp_loss_custom_reference",
+    "yp_match_detections_workspace_bytes", "yp_match_detections",
 )
 
 
@@ -145,6 +148,10 @@ def load():
     L.yp_loss_custom_reference.restype = i32
     L.yp_loss_custom_reference.argtypes = [vp, vp, i32, i32, i32, i32, i32, fp, f32c, f32c, f32c, f32c,
                                            vp, vp, vp, sz, vp]
+    L.yp_match_detections_workspace_bytes.restype = sz
+    L.yp_match_detections_workspace_bytes.argtypes = [i64]
+    L.yp_match_detections.restype = i32
+    L.yp_match_detections.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, i32, f32c, vp, vp, vp, vp, sz, vp]
     _lib = L
     return L
 

@@ -260,6 +260,45 @@ int yp_decode_true_box_grid(const float *d_grid, int batch, int grid_h, int grid
                             int64_t out_cap, int32_t *d_out_count, void *d_workspace,
                             size_t workspace_bytes, void *stream);
 
+/* ---- validation statistics ----------------------------------------------------------- */
+
+/* Kept detections against the ground truth of the same images: the comparison that
+ * train.py:365-366 describes ("check iou of each nms box with each ground truth ..., if above
+ * threshold compare classification") and leaves to the empty comp_nms_gt, train.py:279-280
+ * (get_metrics, train.py:331-340, only prints the two location lists).
+ *   d_det_rows (det_cap, 8) float32, 16-byte aligned: the detection list of yp_write_results /
+ *       yp_detect_yolov3 [image, x1, y1, x2, y2, objectness, class score, class id], ordered by
+ *       descending confidence within an image and class (as those calls emit it); the first
+ *       min(*d_det_count, det_cap) rows are used
+ *   d_gt_boxes (gt_cap, 4) [cx, cy, w, h], d_gt_class (gt_cap,), d_gt_index (gt_cap, 4) int32
+ *       [image, row, col, anchor] ascending by image, *d_gt_count rows: the outputs of
+ *       yp_decode_true_box_grid.  Boxes and detections must be in the same pixel frame.
+ * Rule (PASCAL VOC): a detection's candidate is the ground-truth box of its image and class with
+ * the highest IoU (the lowest row among equals); it is a true positive when that IoU >= iou_thr
+ * (0 < iou_thr <= 1) and no earlier row of the list claimed the same box.  IoU is the plain
+ * geometric one (no +1 term) in binary32: corners of the ground-truth box c -/+ size*0.5,
+ * inter = max(min(x2) - max(x1), 0) * max(min(y2) - max(y1), 0), areas from the corners,
+ * union = (area_det + area_gt) - inter, IoU = inter / union (0 when union <= 0).
+ *   d_det_match [det_cap] int32: the ground-truth row a true positive claims, or YP_MATCH_NONE
+ *       (no box of its class reaches the threshold, and none of another class), YP_MATCH_DUPLICATE
+ *       (its candidate reached the threshold but belongs to an earlier detection),
+ *       YP_MATCH_OTHER_CLASS (only a box of another class reaches the threshold)
+ *   d_det_iou [det_cap] float32 or NULL: highest IoU with any ground-truth box of the image
+ *   d_class_counts [YP_MATCH_PLANES * C] int32: per class id, plane 0 true positives, 1 false
+ *       positives (all kinds), 2 misses (ground-truth boxes nobody claimed), 3 duplicates,
+ *       4 other-class; class ids outside [0, C) are not counted
+ * Deterministic (integer atomics only).  Two kernels and two memsets on the stream; no
+ * allocation, no host synchronisation. */
+#define YP_MATCH_PLANES 5
+enum { YP_MATCH_NONE = -1, YP_MATCH_DUPLICATE = -2, YP_MATCH_OTHER_CLASS = -3 };
+size_t yp_match_detections_workspace_bytes(int64_t gt_cap);
+int yp_match_detections(const float *d_det_rows, const int32_t *d_det_count, int64_t det_cap,
+                        const float *d_gt_boxes, const float *d_gt_class,
+                        const int32_t *d_gt_index, const int32_t *d_gt_count, int64_t gt_cap,
+                        int num_classes, float iou_thr, int32_t *d_det_match, float *d_det_iou,
+                        int32_t *d_class_counts, void *d_workspace, size_t workspace_bytes,
+                        void *stream);
+
 /* ---- backward of the reference decode (for the training losses) ---------------------- */
 
 /* Gradient of DetectNet.predict_transform, detect_net.py:152-183, with respect to its input,

@@ -279,3 +279,82 @@ def n_rescale(det, inp_dim, frame):
     for col, pad, top in ((1, pad_x, im_w), (2, pad_y, im_h), (3, pad_x, im_w), (4, pad_y, im_h)):
         out[:, col] = np.minimum(np.maximum((out[:, col] - pad) / scale, f(0.0)), top)
     return out
+
+
+# ------------------------------------------------------------- detections against ground truth
+
+MATCH_NONE, MATCH_DUPLICATE, MATCH_OTHER_CLASS = -1, -2, -3
+
+
+def match_iou(det, gt):
+    """Plain geometric IoU (no +1 term) of a corner box det [x1, y1, x2, y2] with a centre/size
+    box gt [cx, cy, w, h], binary32 in a fixed operation order."""
+    d = [f32(v) for v in det]
+    g = [f32(v) for v in gt]
+    hw, hh = g[2] * f32(0.5), g[3] * f32(0.5)
+    gx1, gy1, gx2, gy2 = g[0] - hw, g[1] - hh, g[0] + hw, g[1] + hh
+    ix = max(min(d[2], gx2) - max(d[0], gx1), f32(0.0))
+    iy = max(min(d[3], gy2) - max(d[1], gy1), f32(0.0))
+    inter = f32(ix * iy)
+    area_d = f32(f32(d[2] - d[0]) * f32(d[3] - d[1]))
+    area_g = f32(f32(gx2 - gx1) * f32(gy2 - gy1))
+    uni = f32(f32(area_d + area_g) - inter)
+    return f32(inter / uni) if uni > 0 else f32(0.0)
+
+
+def match_detections(rows, gt_index, gt_boxes, gt_class, num_classes, iou_thr):
+    """The comparison train.py:365-366 describes and the empty comp_nms_gt (train.py:279-280)
+    was meant to hold, by the PASCAL-VOC rule, as a sequential loop: detections in list order;
+    the candidate of a detection is the ground-truth box of its image and class with the highest
+    IoU (first among equals); true positive when that IoU >= iou_thr and the box is still free.
+    Returns (det_match (D,) int32, det_iou (D,) float32, class_counts (5, C) int32 with planes
+    true positives, false positives, misses, duplicates, other-class)."""
+    rows = np.asarray(rows, f32).reshape(-1, 8)
+    gt_index = np.asarray(gt_index, np.int64).reshape(-1, 4)
+    gt_boxes = np.asarray(gt_boxes, f32).reshape(-1, 4)
+    gt_class = np.asarray(gt_class, f32).reshape(-1)
+    thr = f32(iou_thr)
+    C = int(num_classes)
+    taken = np.zeros(len(gt_boxes), bool)
+    det_match = np.full(len(rows), MATCH_NONE, np.int32)
+    det_iou = np.zeros(len(rows), f32)
+    counts = np.zeros((5, C), np.int32)
+
+    def bump(plane, cls):
+        if 0 <= cls < C:
+            counts[plane, int(cls)] += 1
+
+    for d, r in enumerate(rows):
+        img, cls = int(r[0]), r[7]
+        best_any, best_same, best_other, cand = f32(0), f32(0), f32(0), -1
+        for g in np.flatnonzero(gt_index[:, 0] == img):
+            iou = match_iou(r[1:5], gt_boxes[g])
+            best_any = max(best_any, iou)
+            if gt_class[g] == cls:
+                if iou > best_same:
+                    best_same, cand = iou, int(g)
+            elif iou > best_other:
+                best_other = iou
+        det_iou[d] = best_any
+        if cand >= 0 and best_same >= thr:
+            if not taken[cand]:
+                taken[cand] = True
+                det_match[d] = cand
+                bump(0, cls)
+                continue
+            det_match[d] = MATCH_DUPLICATE
+            bump(3, cls)
+        elif best_other >= thr:
+            det_match[d] = MATCH_OTHER_CLASS
+            bump(4, cls)
+        bump(1, cls)
+    for g in np.flatnonzero(~taken):
+        bump(2, gt_class[g])
+    return det_match, det_iou, counts
+
+
+def precision_recall(class_counts):
+    """Per class (precision, recall) from the count planes; NaN where undefined."""
+    c = np.asarray(class_counts, np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return c[0] / (c[0] + c[1]), c[0] / (c[0] + c[2])

@@ -171,6 +171,22 @@ int main()
     CHECK(yp_profile_stop(nullptr, nullptr, nullptr, nullptr) == YP_ERR_ARG);
     CHECK(yp_profile_start(0) == YP_ERR_ARG);
 
+    // validation statistics
+    CHECK(yp_match_detections_workspace_bytes(1) == 256 && yp_match_detections_workspace_bytes(0) == 0);
+    CHECK(yp_match_detections_workspace_bytes(((int64_t)1 << 30) + 1) == 0);
+    CHECK(yp_match_detections(nullptr, fi, 10, ff, ff, fi, fi, 10, 5, 0.5f, fi, ff, fi, fake, big, nullptr) ==
+          YP_ERR_ARG);
+    CHECK(yp_match_detections(ff, fi, 0, ff, ff, fi, fi, 10, 5, 0.5f, fi, ff, fi, fake, big, nullptr) == YP_ERR_ARG);
+    CHECK(yp_match_detections(ff, fi, 10, ff, ff, fi, fi, -3, 5, 0.5f, fi, ff, fi, fake, big, nullptr) == YP_ERR_ARG);
+    CHECK(yp_match_detections(ff, fi, 10, ff, ff, fi, fi, 10, 4097, 0.5f, fi, ff, fi, fake, big, nullptr) ==
+          YP_ERR_ARG);
+    CHECK(yp_match_detections(ff, fi, 10, ff, ff, fi, fi, 10, 5, __builtin_nanf(""), fi, ff, fi, fake, big,
+                              nullptr) == YP_ERR_ARG);
+    CHECK(yp_match_detections(ff + 1, fi, 10, ff, ff, fi, fi, 10, 5, 0.5f, fi, ff, fi, fake, big, nullptr) ==
+          YP_ERR_ARG);
+    CHECK(yp_match_detections(ff, fi, 10, ff, ff, fi, fi, 10, 5, 0.5f, fi, nullptr, fi, fake, 8, nullptr) ==
+          YP_ERR_WORKSPACE);
+
     if (g_fail) {
         std::printf("%d of %d checks failed\n", g_fail, g_checks);
         return 1;

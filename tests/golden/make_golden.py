@@ -133,7 +133,86 @@ def golden_grid_codec():
         grid=grids, mask=masks, boxes=np.concatenate(boxes), locations=np.concatenate(locs))
 
 
+def match_hand_case():
+    """Four images, answers known by hand at threshold 0.5.  Ground truth [cx, cy, w, h]:
+    A (image 0, class 1) = corners 50..150; B (image 0, class 2) = corners 375..425;
+    C (image 1, class 1) = [150, 100, 250, 300]; D (image 3, class 3), which nothing detects."""
+    gt_index = np.array([[0, 3, 3, 0], [0, 9, 9, 1], [1, 5, 5, 2], [3, 1, 1, 0]], np.int32)
+    gt_boxes = np.array([[100, 100, 100, 100], [400, 400, 50, 50], [200, 200, 100, 200],
+                         [60, 60, 40, 40]], np.float32)
+    gt_class = np.array([1, 2, 1, 3], np.float32)
+    rows = np.array([
+        [0, 50, 50, 150, 150, .9, .9, 1],          # IoU 1 with A: true positive
+        [0, 60, 50, 150, 150, .8, .8, 1],          # IoU 0.9 with A, already claimed: duplicate
+        [0, 375, 375, 425, 425, .7, .7, 1],        # IoU 1 with B, which is class 2: other class
+        [0, 1000, 1000, 1100, 1100, .9, .9, 2],    # overlaps nothing; B stays unclaimed
+        [1, 150, 100, 250, 200, .9, .9, 1],        # IoU exactly 0.5 with C: true positive (>=)
+        [2, 10, 10, 20, 20, .9, .9, 0],            # an image without ground truth
+    ], np.float32)
+    want_match = np.array([0, -2, -3, -1, 2, -1], np.int32)
+    want_counts = np.zeros((5, 5), np.int32)
+    want_counts[0, 1] = 2
+    want_counts[1, [0, 1, 2]] = [1, 2, 1]
+    want_counts[2, [2, 3]] = 1
+    want_counts[3, 1] = 1
+    want_counts[4, 1] = 1
+    return rows, gt_index, gt_boxes, gt_class, want_match, want_counts
+
+
+def match_random_case(seed=404, n_images=6, num_classes=5):
+    """Seeded scene: up to 12 ground-truth boxes per image; detections are jittered copies of
+    them (some twice, some with another class) plus stray boxes, by descending score per image."""
+    rs = np.random.RandomState(seed)
+    gi, gb, gc, rows = [], [], [], []
+    for b in range(n_images):
+        n = int(rs.randint(0, 13)) if b != 2 else 0
+        boxes = np.stack([rs.uniform(100, 1800, n), rs.uniform(100, 1200, n), rs.uniform(20, 400, n),
+                          rs.uniform(20, 400, n)], 1).astype(np.float32)
+        cls = rs.randint(0, num_classes, n).astype(np.float32)
+        for k in range(n):
+            gi.append([b, k, k, 0]); gb.append(boxes[k]); gc.append(cls[k])
+        dets = []
+        for k in range(n):
+            for _ in range(int(rs.randint(0, 3))):
+                j = rs.normal(0, 0.12, 4) * boxes[k, [2, 3, 2, 3]]
+                cx, cy, w, h = boxes[k]
+                c = cls[k] if rs.rand() > 0.2 else float((cls[k] + 1) % num_classes)
+                dets.append([b, cx - w / 2 + j[0], cy - h / 2 + j[1], cx + w / 2 + j[2], cy + h / 2 + j[3],
+                             rs.uniform(0.5, 1), 0.9, c])
+        for _ in range(int(rs.randint(0, 4))):
+            x, y = rs.uniform(0, 1800), rs.uniform(0, 1200)
+            dets.append([b, x, y, x + rs.uniform(5, 300), y + rs.uniform(5, 300), rs.uniform(0.5, 1), 0.9,
+                         float(rs.randint(0, num_classes))])
+        dets.sort(key=lambda r: -r[5])
+        rows += dets
+    return (np.array(rows, np.float32).reshape(-1, 8), np.array(gi, np.int32).reshape(-1, 4),
+            np.array(gb, np.float32).reshape(-1, 4), np.array(gc, np.float32))
+
+
+def golden_match():
+    rows, gi, gb, gc, want_match, want_counts = match_hand_case()
+    m, iou, counts = npo.match_detections(rows, gi, gb, gc, 5, 0.5)
+    assert np.array_equal(m, want_match) and np.array_equal(counts, want_counts)
+    assert iou[0] == 1.0 and iou[4] == 0.5 and abs(iou[1] - 0.9) < 1e-6 and iou[3] == 0.0
+    out = {"hand_rows": rows, "hand_gt_index": gi, "hand_gt_boxes": gb, "hand_gt_class": gc,
+           "hand_match": m, "hand_iou": iou, "hand_counts": counts}
+    rows, gi, gb, gc = match_random_case()
+    for name, thr in (("t05", 0.5), ("t06", 0.6), ("t03", 0.3)):
+        m, iou, counts = npo.match_detections(rows, gi, gb, gc, 5, thr)
+        assert counts[0].sum() > 0 and counts[3].sum() > 0 and counts[4].sum() > 0 and counts[2].sum() > 0
+        # every ground-truth box is either claimed once or missed
+        assert counts[0].sum() + counts[2].sum() == len(gb) and len(set(m[m >= 0])) == (m >= 0).sum()
+        out.update({"rand_match_" + name: m, "rand_counts_" + name: counts})
+    out.update({"rand_rows": rows, "rand_gt_index": gi, "rand_gt_boxes": gb, "rand_gt_class": gc,
+                "rand_iou": iou})
+    np.savez_compressed(os.path.join(HERE, "match_cases.npz"), **out)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["match"]:       # only the newest file, the others stay byte-identical
+        golden_match()
+        raise SystemExit(0)
+    golden_match()
     golden_grid_codec()
     golden_reference_mode()
     golden_yolov3_mode()

@@ -173,7 +173,7 @@ def test_abi_validation_layer_under_host_sanitizers():
     os.makedirs(build, exist_ok=True)
     exe = os.path.join(build, "abi_sanitized")
     srcs = [os.path.join(here, "abi_sanitized.cpp")] + [os.path.join(csrc, f) for f in
-                                                         ("yolopost.hip", "gridcodec.hip", "decode_grad.hip")]
+                                                         ("yolopost.hip", "gridcodec.hip", "decode_grad.hip", "metrics.hip")]
     deps = srcs + [os.path.join(csrc, f) for f in ("yp_graph.h", "yp_math.h", "yp_tile.h")] + \
         [os.path.join(here, "..", "include", "yolopost.h")]
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(f) for f in deps):

@@ -60,6 +60,28 @@ def _worker(rank, world, port, q):
         h = pg.gather(torch.tensor([2], dtype=torch.int64), async_op=True)
         h.wait()
         ok = ok and pg.unpack()[1] == [2] * world
+        # several sets per launch in one collective: per-set counts in the header row, one slab
+        # of `cap` rows per set; a count beyond the capacity is reported as it is, rows capped
+        sg = d.PaddedSetGather(3, 4, 8, torch.device("cpu"))
+        ok = ok and tuple(sg.rows.shape) == (3, 4, 8) and sg.rows.data_ptr() == sg.send[1].data_ptr()
+        per_set = [rank + 1, 0, 9 if rank == 1 else 2]
+        for s_, c in enumerate(per_set):
+            sg.rows[s_, :, 0] = float(100 * rank + 10 * s_)
+            sg.rows[s_, :, 1] = torch.arange(4, dtype=torch.float32)
+        sg.gather(torch.tensor(per_set, dtype=torch.int32))
+        got8, c8 = sg.unpack()
+        for r in range(world):
+            want_c = [r + 1, 0, 9 if r == 1 else 2]
+            ok = ok and c8[r] == want_c
+            for s_, c in enumerate(want_c):
+                blk = got8[r][s_]
+                ok = ok and blk.shape == (min(c, 4), 8)
+                ok = ok and bool((blk[:, 0] == float(100 * r + 10 * s_)).all())
+                ok = ok and torch.equal(blk[:, 1], torch.arange(min(c, 4), dtype=torch.float32))
+        # a launch that used fewer sets than the buffer holds: the unused counts read as zero
+        sg.gather(torch.tensor([3, 3, 3], dtype=torch.int64), n_used=2)
+        _, c9 = sg.unpack()
+        ok = ok and c9 == [[3, 3, 0]] * world
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
