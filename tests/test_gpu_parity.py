@@ -112,7 +112,7 @@ def test_v3_detect_vs_libm_oracle_ties_are_reported(pkg, dev, name, B, inp_dim, 
     confidence threshold, a pair with IoU at the NMS threshold and |IoU - thr|, or a consequence
     of such a row); a difference without such an explanation fails the test.  The number of pairs
     the kernels themselves found at the threshold is printed beside it."""
-    from tie_report import differences, format_report
+    from tie_report import align, differences, format_report
     syn, util = pkg.synthetic, pkg.util
     chunks = [syn.make_heads(min(16, B - lo), inp_dim, 5, seed=seed * 1000 + lo, clustered=clustered)
               for lo in range(0, B, 16)]
@@ -127,7 +127,9 @@ def test_v3_detect_vs_libm_oracle_ties_are_reported(pkg, dev, name, B, inp_dim, 
         print(format_report(diffs))
     assert all(d["reason"] is not None for d in diffs), format_report([d for d in diffs if d["reason"] is None])
     if not diffs:
-        assert got.shape == want.shape
+        # the same detections on both sides; two rows of a class whose objectness agrees to the
+        # last bits may come in either order, so pair the rows up before comparing values
+        want = want[align(got, want)]
         assert np.array_equal(got[:, [0, 7]], want[:, [0, 7]])
         assert rel_err(got[:, 5:7], want[:, 5:7]) < REL
         # corners are differences (cx - w/2): measure their error against the box's own scale

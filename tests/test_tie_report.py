@@ -62,3 +62,31 @@ def test_a_difference_without_a_tie_is_flagged():
     d = differences(a, b, 0.5, 0.4)
     assert len(d) == 1 and d[0]["reason"] is None and "UNEXPLAINED" in format_report(d)
     assert abs(float(iou_plus1([0, 0, 1, 0], [[1, 0, 2, 0]])[0]) - 1.0 / 3.0) < 1e-12
+
+
+def test_align_pairs_rows_whose_order_flipped():
+    """Two outputs with the same detections where two rows of one class swap places (objectness
+    equal to the last bits): align() finds the permutation, and refuses a row without counterpart."""
+    from tie_report import align
+    rs = np.random.RandomState(5)
+    n = 40
+    a = np.zeros((n, 8), np.float32)
+    a[:, 0] = np.repeat([0, 1], n // 2)
+    a[:, 7] = np.tile(np.repeat([0, 2], n // 4), 2)
+    a[:, 1:3] = rs.uniform(0, 300, (n, 2))
+    a[:, 3:5] = a[:, 1:3] + rs.uniform(5, 80, (n, 2))
+    for g in range(4):                                   # objectness descending inside each group
+        a[g * 10:(g + 1) * 10, 5] = np.sort(rs.uniform(0.5, 1, 10))[::-1]
+    a[:, 6] = rs.uniform(0.3, 1, n)
+    a[13, 5] = a[12, 5]                                  # a tie in objectness
+    b = a * np.float32(1 + 3e-7)
+    b[:, [0, 7]] = a[:, [0, 7]]
+    b[[12, 13]] = b[[13, 12]]                            # the other side orders the tie the other way
+    p = align(a, b)
+    assert sorted(p) == list(range(n)) and p[12] == 13 and p[13] == 12
+    assert np.abs(b[p] - a).max() < 1e-3
+    c = b.copy()
+    c[5, 1:5] += 50.0
+    import pytest
+    with pytest.raises(ValueError):
+        align(a, c)

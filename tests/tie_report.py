@@ -30,13 +30,15 @@ def iou_plus1(a, b):
     return inter / (area_a + area_b - inter)
 
 
-def _match(a, b):
+def _match(a, b, pairs=None):
     """Indices of the rows of a without a counterpart in b and vice versa (rows (n, 8) of one
     image and class, both sorted by objectness descending as write_results emits them).  Only
     rows of b whose objectness lies within MATCH of the row's are candidates: a window found by
-    bisection, since b is sorted."""
+    bisection, since b is sorted.  `pairs` (a list) receives the (row of a, row of b) matches."""
     used = np.zeros(len(b), bool)
     only_a = []
+    if pairs is None:
+        pairs = []
     neg_obj_b = -b[:, 5].astype(np.float64)          # ascending
     for i, r in enumerate(a):
         lo = int(np.searchsorted(neg_obj_b, -float(r[5]) - MATCH, side="left"))
@@ -50,9 +52,38 @@ def _match(a, b):
                 found = lo + int(j[0])
         if found >= 0:
             used[found] = True
+            pairs.append((i, found))
         else:
             only_a.append(i)
     return only_a, list(np.flatnonzero(~used))
+
+
+def align(rows_a, rows_b):
+    """Permutation p with rows_b[p[i]] the counterpart of rows_a[i], for two outputs that hold the
+    same detections (no one-sided rows): inside an (image, class) group the order may differ where
+    two objectness values are equal to the last bits.  Raises ValueError when a row has no
+    counterpart."""
+    if rows_a.shape != rows_b.shape:
+        raise ValueError("different numbers of rows")
+    perm = np.arange(len(rows_a))
+    key_a = rows_a[:, 0].astype(np.int64) * 4096 + rows_a[:, 7].astype(np.int64)
+    key_b = rows_b[:, 0].astype(np.int64) * 4096 + rows_b[:, 7].astype(np.int64)
+    for key in np.union1d(key_a, key_b):
+        ia, ib = np.flatnonzero(key_a == key), np.flatnonzero(key_b == key)
+        if len(ia) != len(ib):
+            raise ValueError("group %d holds %d and %d rows" % (key, len(ia), len(ib)))
+        a, b = rows_a[ia], rows_b[ib]
+        scale = np.maximum(1.0, np.abs(a[:, 1:5]).max(1))
+        if (np.abs(a[:, 1:5] - b[:, 1:5]).max(1) <= MATCH * scale).all():
+            perm[ia] = ib
+            continue
+        pairs = []
+        only_a, only_b = _match(a, b, pairs)
+        if only_a or only_b:
+            raise ValueError("group %d: rows without a counterpart" % key)
+        for i, j in pairs:
+            perm[ia[i]] = ib[j]
+    return perm
 
 
 def differences(rows_a, rows_b, conf, thr, name_a="A", name_b="B"):
