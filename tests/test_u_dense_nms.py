@@ -67,3 +67,59 @@ def test_dense_flag_is_chosen_from_the_configuration(pkg, dev):
     assert util.YoloV3Post(1, 416, 5, 0.5, 0.4, device=dev).dense_nms is False
     assert util.YoloV3Post(1, 96, 5, 0.001, 0.4, device=dev).dense_nms is False       # few anchors
     assert util.YoloV3Post(1, 416, 5, 0.5, 0.4, device=dev, dense_nms=True).dense_nms is True
+
+
+def test_cfg5_full_batch_properties(pkg, dev):
+    """The whole per-GPU batch of BASELINE.json's cfg5 (32 images at 1920x1280, conf 0.001: about
+    29,500 candidates per (image, class)) -- too large for the oracle in a test, so checked through
+    properties that do not depend on the size: both NMS paths give the same bytes; images are
+    independent (the first image alone gives the same rows, and those equal the oracle's); rows
+    are ordered image -> class -> objectness; counts add up; and inside a segment no two kept
+    boxes reach the threshold (what greedy NMS guarantees)."""
+    import os
+    syn, util = pkg.synthetic, pkg.util
+    B = int(os.environ.get("YP_TEST_CFG5_BATCH", "32"))
+    inp_dim, conf, thr = (1280, 1920), 0.001, 0.4
+    chunks = [syn.make_heads(min(16, B - lo), inp_dim, 5, seed=4000 + lo) for lo in range(0, B, 16)]
+    heads = [torch.cat([c[h] for c in chunks], 0).contiguous() for h in range(3)]
+    dheads = [h.to(dev) for h in heads]
+    eng = util.YoloV3Post(B, inp_dim, 5, conf, thr, device=dev)
+    assert eng.dense_nms is True
+    got = eng.detect(dheads).clone()
+    surv, kept, _ = eng.segment_stats()
+    assert surv.shape == (B, 5) and surv.min() > 768
+    assert int(kept.sum()) == got.shape[0] and (kept <= surv).all() and (kept > 0).all()
+    # the one-workgroup-per-segment path: same bytes
+    other = util.YoloV3Post(B, inp_dim, 5, conf, thr, device=dev, dense_nms=False).detect(dheads)
+    assert torch.equal(got, other)
+    del other
+    # order: image, then class, then objectness descending; every row passed the filter
+    img, cls, obj = got[:, 0], got[:, 7], got[:, 5]
+    key = img.to(torch.int64) * 8 + cls.to(torch.int64)
+    assert bool((key[1:] >= key[:-1]).all())
+    same = key[1:] == key[:-1]
+    assert bool((obj[1:][same] <= obj[:-1][same]).all())
+    assert bool((obj > conf).all())
+    counts = torch.bincount(key, minlength=B * 8).view(B, 8)[:, :5].cpu().numpy()
+    assert np.array_equal(counts, kept)
+    # images are independent: image 0 alone gives the same rows, and they are the oracle's
+    first = util.YoloV3Post(1, inp_dim, 5, conf, thr, device=dev).detect([h[:1].contiguous() for h in dheads])
+    n0 = int(kept[0].sum())
+    assert torch.equal(first, got[:n0])
+    want, _, _ = oracle.n_detect([h[:1].numpy() for h in heads], inp_dim, syn.YOLOV3_ANCHORS, 5, conf, thr)
+    assert np.array_equal(first.cpu().numpy(), want)
+    # no two kept boxes of a segment reach the threshold (pixel-inclusive IoU, as the path defines it)
+    for b, c in ((0, 0), (B - 1, 4), (B // 2, 2)):
+        seg = got[(img == b) & (cls == c)][:, 1:5]
+        n = seg.shape[0]
+        area = (seg[:, 2] - seg[:, 0] + 1) * (seg[:, 3] - seg[:, 1] + 1)
+        worst = 0.0
+        for lo in range(0, n, 2048):
+            a = seg[lo:lo + 2048]
+            iw = (torch.minimum(a[:, None, 2], seg[None, :, 2]) - torch.maximum(a[:, None, 0], seg[None, :, 0]) + 1).clamp(min=0)
+            ih = (torch.minimum(a[:, None, 3], seg[None, :, 3]) - torch.maximum(a[:, None, 1], seg[None, :, 1]) + 1).clamp(min=0)
+            inter = iw * ih
+            iou = inter / (area[lo:lo + 2048, None] + area[None, :] - inter)
+            iou[torch.arange(a.shape[0]), torch.arange(lo, lo + a.shape[0])] = 0.0      # a box with itself
+            worst = max(worst, float(iou.max()))
+        assert worst < thr, (b, c, worst)
