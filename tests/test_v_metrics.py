@@ -136,6 +136,96 @@ def test_detection_rows_packing(pkg):
     assert np.array_equal(rows[:6].numpy(), np.array(want, np.float32))
 
 
+def _emulated_library():
+    """csrc/metrics.hip compiled with g++ against tests/host_emul (workgroups as OS threads that
+    meet at a barrier where the kernel synchronises): the kernels' own source, run on the CPU."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ is not installed here")
+    build = os.path.join(HERE, "_build")
+    os.makedirs(build, exist_ok=True)
+    so = os.path.join(build, "libmetrics_emul.so")
+    deps = [os.path.join(HERE, "host_emul", "emul_metrics.cpp"), os.path.join(HERE, "host_emul", "hip", "hip_runtime.h"),
+            os.path.join(HERE, "..", "2d_object_detection_amd", "csrc", "metrics.hip"),
+            os.path.join(HERE, "..", "include", "yolopost.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in deps):
+        subprocess.check_call([gxx, "-std=c++20", "-O1", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
+                               "-I" + os.path.join(HERE, "host_emul"), "-I" + os.path.join(HERE, "..", "include"),
+                               "-o", so, deps[0]])
+    return ctypes.CDLL(so)
+
+
+def _run_emulated(lib, rows, gi, gb, gc, num_classes, thr, det_cap, gt_cap):
+    D, G = len(rows), len(gb)
+
+    def pad(a, n, fill, dtype):
+        out = np.full((n,) + a.shape[1:], fill, dtype)
+        out[:len(a)] = a
+        return out
+    base = np.zeros(det_cap * 8 + 4, np.float32)                      # a 16-byte aligned view for the float4 loads
+    off = (-base.ctypes.data // 4) % 4
+    h_rows = base[off:off + det_cap * 8].reshape(det_cap, 8)
+    h_rows[:] = 7.0
+    h_rows[:D] = rows.reshape(-1, 8)
+    gbase = np.zeros(gt_cap * 4 + 4, np.float32)
+    goff = (-gbase.ctypes.data // 4) % 4
+    h_gb = gbase[goff:goff + gt_cap * 4].reshape(gt_cap, 4)
+    h_gb[:] = 50.0
+    h_gb[:G] = gb.reshape(-1, 4)
+    h_gi, h_gc = pad(gi.reshape(-1, 4), gt_cap, 0, np.int32), pad(gc, gt_cap, 1.0, np.float32)
+    nd, ng = np.array([D], np.int32), np.array([G], np.int32)
+    match = np.full(det_cap, -77, np.int32)
+    iou = np.full(det_cap, -7.0, np.float32)
+    counts = np.full((5, num_classes), -5, np.int32)
+    lib.yp_match_detections_workspace_bytes.restype = ctypes.c_size_t
+    lib.yp_match_detections_workspace_bytes.argtypes = [ctypes.c_int64]
+    need = lib.yp_match_detections_workspace_bytes(gt_cap)
+    wbase = np.zeros(need + 256, np.uint8)
+    woff = (-wbase.ctypes.data) % 256
+    vp = ctypes.c_void_p
+    lib.yp_match_detections.argtypes = [vp, vp, ctypes.c_int64, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int32,
+                                        ctypes.c_float, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    rc = lib.yp_match_detections(h_rows.ctypes.data, nd.ctypes.data, det_cap, h_gb.ctypes.data, h_gc.ctypes.data,
+                                 h_gi.ctypes.data, ng.ctypes.data, gt_cap, num_classes, thr, match.ctypes.data,
+                                 iou.ctypes.data, counts.ctypes.data, wbase.ctypes.data + woff, need, None)
+    assert rc == 0
+    assert (match[D:] == -77).all() and (iou[D:] == -7.0).all()
+    return match[:D], iou[:D], counts
+
+
+def test_match_kernels_under_host_emulation():
+    """k_match_claim / k_match_count themselves -- the source the GPU compiles -- executed on the
+    CPU by the emulation in tests/host_emul, against the oracle: golden cases, scenes with several
+    workgroups of detections, empty sides, capacities beyond the counts, and a class count that
+    takes the kernels' global-atomics branch (5 x 500 cells exceed the LDS histogram)."""
+    lib = _emulated_library()
+    g = golden()
+    m, iou, counts = _run_emulated(lib, g["hand_rows"], g["hand_gt_index"], g["hand_gt_boxes"], g["hand_gt_class"],
+                                   5, 0.5, 6, 4)
+    assert np.array_equal(m, g["hand_match"]) and np.array_equal(iou, g["hand_iou"])
+    assert np.array_equal(counts, g["hand_counts"])
+    for name, thr in (("t05", 0.5), ("t06", 0.6), ("t03", 0.3)):
+        m, iou, counts = _run_emulated(lib, g["rand_rows"], g["rand_gt_index"], g["rand_gt_boxes"],
+                                       g["rand_gt_class"], 5, thr, 300, 70)
+        assert np.array_equal(m, g["rand_match_" + name]) and np.array_equal(counts, g["rand_counts_" + name])
+        assert np.array_equal(iou, g["rand_iou"])
+    for seed, n_images, C, thr in ((1, 40, 5, 0.5), (4, 60, 500, 0.5), (5, 1, 5, 1.0), (3, 60, 3, 0.25)):
+        rows, gi, gb, gc = make_golden.match_random_case(seed=seed, n_images=n_images, num_classes=min(C, 7))
+        want = npo.match_detections(rows, gi, gb, gc, C, thr)
+        got = _run_emulated(lib, rows, gi, gb, gc, C, thr, len(rows) + 300, len(gb) + 5)
+        assert len(rows) > 256 or n_images == 1
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), (seed, C)
+    rows, gi, gb, gc = make_golden.match_random_case(seed=11, n_images=3)
+    m, _, counts = _run_emulated(lib, np.zeros((0, 8), np.float32), gi, gb, gc, 5, 0.5, 1, len(gb))
+    assert len(m) == 0 and counts[2].sum() == len(gb) and counts[[0, 1, 3, 4]].sum() == 0
+    m, iou, counts = _run_emulated(lib, rows, np.zeros((0, 4), np.int32), np.zeros((0, 4), np.float32),
+                                   np.zeros((0,), np.float32), 5, 0.5, len(rows), 1)
+    assert (m == -1).all() and (iou == 0).all() and counts[1].sum() == len(rows) and counts[[0, 2]].sum() == 0
+
+
 # ---------------------------------------------------------------------------------- GPU
 
 def run_abi(pkg, dev, rows, gi, gb, gc, num_classes, thr, det_cap=None, gt_cap=None, want_iou=True):
