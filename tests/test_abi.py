@@ -187,3 +187,25 @@ def test_abi_validation_layer_under_host_sanitizers():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.strip().splitlines()[-1].startswith("ok "), out.stdout[-500:]
     assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-4000:]
+
+
+def test_flag_policy_of_the_python_engines(pkg):
+    """Which YpParams.flags the host layer sets (pure host logic, no device needed)."""
+    util, L = pkg.util, pkg._lib
+    # the large-segment path: explicit choice wins, otherwise low thresholds on many anchors
+    assert util._dense_nms(None, 0.001, 151200, 5) is True
+    assert util._dense_nms(None, 0.001, 10647, 5) is True
+    assert util._dense_nms(None, 0.001, 10647, 80) is False       # few anchors per class
+    assert util._dense_nms(None, 0.5, 151200, 5) is False
+    assert util._dense_nms(False, 0.001, 151200, 5) is False and util._dense_nms(True, 0.9, 10, 5) is True
+    p = util._v3_params(4, 5, 0.5, 0.4)
+    assert (p.mode, p.batch, p.num_classes, p.max_out, p.flags) == (L.YP_MODE_YOLOV3, 4, 5, 0, 0)
+    p = util._v3_params(4, 5, 0.5, 0.4, batch_offset=8, dense=True, frame=(1280, 1920))
+    assert p.flags == L.YP_FLAG_DENSE_NMS | L.YP_FLAG_RESCALE and p.batch_offset == 8
+    assert (p.im_h, p.im_w) == (1280.0, 1920.0)
+    # and the library accepts exactly that combination (rejected here only for its fake pointers' sizes)
+    lib = L.load()
+    fake = ctypes.c_void_p(0x1000)
+    heads = (L.YpHead * 1)(L.make_head(None, 13, 13, [(1, 1)] * 3, 32, 32))
+    heads[0].data = 0x1000
+    assert lib.yp_detect_yolov3(heads, 1, ctypes.byref(p), fake, 10, fake, None, fake, 16, None) == -2   # workspace, not flags
