@@ -210,16 +210,21 @@ __device__ __forceinline__ u64 lanes_below(int lane) { return (1ull << lane) - 1
 // Single-instruction max/min.  For non-NaN operands they equal (a > b ? a : b) and
 // (a < b ? a : b); written as asm because the compiler pairs every such select with a
 // compare, and canonicalises the operands of the fmaxf/fminf/fmed3 builtins first.
+// (The CPU emulation the tests run these kernels under defines the two macros itself.)
+#ifndef YP_VMAX_F32
+#define YP_VMAX_F32(r, a, b) asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b))
+#define YP_VMIN_F32(r, a, b) asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b))
+#endif
 __device__ __forceinline__ float vmax(float a, float b)
 {
     float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    YP_VMAX_F32(r, a, b);
     return r;
 }
 __device__ __forceinline__ float vmin(float a, float b)
 {
     float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    YP_VMIN_F32(r, a, b);
     return r;
 }
 

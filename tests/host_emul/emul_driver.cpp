@@ -1,0 +1,89 @@
+// Replays one recorded call of yp_detect_yolov3_multi through the host emulation of the kernels
+// (built with AddressSanitizer + UndefinedBehaviorSanitizer by the Makefile in this directory)
+// and compares the output with the expected rows stored in the case file.  Every buffer is a heap
+// block of exactly the size the ABI documents, so a kernel that reads or writes one element too far
+// is reported by the sanitizer.  Case file (little endian), written by tests/test_y_emulation.py:
+//   int32  magic 0x31455059, n_sets, batch, classes, n_heads, flags, cap, batch_offset
+//   float  conf, nms, im_h, im_w
+//   per head: int32 grid_h, grid_w, anchors; float stride_x, stride_y, anchors[16]
+//   per set, per head: float data[batch * anchors * (5 + classes) * grid_h * grid_w]
+//   per set: int32 count; float rows[min(count, cap) * 8]
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "yolopost.h"
+
+extern "C" void emul_stats(long *out, int reset);
+
+static bool read_exact(FILE *f, void *p, size_t n) { return n == 0 || std::fread(p, 1, n, f) == n; }
+
+int main(int argc, char **argv)
+{
+    if (argc != 2) return 2;
+    FILE *f = std::fopen(argv[1], "rb");
+    if (!f) return 2;
+    int32_t h[8];
+    float t[4];
+    if (!read_exact(f, h, sizeof h) || !read_exact(f, t, sizeof t) || h[0] != 0x31455059) return 2;
+    const int n_sets = h[1], B = h[2], C = h[3], n_heads = h[4], flags = h[5], cap = h[6];
+    std::vector<YpHead> heads((size_t)n_sets * n_heads);
+    std::vector<size_t> elems(n_heads);
+    for (int k = 0; k < n_heads; ++k) {
+        int32_t g[3];
+        float s[2 + 2 * YP_MAX_ANCHORS];
+        if (!read_exact(f, g, sizeof g) || !read_exact(f, s, sizeof s)) return 2;
+        for (int set = 0; set < n_sets; ++set) {
+            YpHead &d = heads[(size_t)set * n_heads + k];
+            std::memset(&d, 0, sizeof d);
+            d.grid_h = g[0]; d.grid_w = g[1]; d.num_anchors = g[2];
+            d.stride_x = s[0]; d.stride_y = s[1];
+            std::memcpy(d.anchors, s + 2, sizeof d.anchors);
+        }
+        elems[k] = (size_t)B * g[2] * (5 + C) * g[0] * g[1];
+    }
+    for (int set = 0; set < n_sets; ++set)
+        for (int k = 0; k < n_heads; ++k) {
+            float *data = (float *)std::aligned_alloc(16, (elems[k] * 4 + 15) / 16 * 16);
+            if (!read_exact(f, data, elems[k] * 4)) return 2;
+            heads[(size_t)set * n_heads + k].data = data;
+        }
+    YpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.mode = YP_MODE_YOLOV3; p.batch = B; p.num_classes = C; p.max_out = 0;
+    p.conf_thr = t[0]; p.nms_thr = t[1]; p.im_h = t[2]; p.im_w = t[3];
+    p.batch_offset = h[7]; p.flags = flags;
+    const size_t need = yp_detect_yolov3_workspace_bytes(heads.data(), n_heads, n_sets * B, C);
+    if (need == 0) { std::printf("unsupported geometry\n"); return 1; }
+    void *ws = std::aligned_alloc(256, need);
+    float *out = (float *)std::aligned_alloc(16, (size_t)n_sets * cap * 32);
+    int32_t *count = (int32_t *)std::malloc((size_t)n_sets * 4);
+    int32_t *stats = (int32_t *)std::malloc((size_t)n_sets * 4 * B * C * 4);
+    std::memset(ws, 0xA5, need);
+    std::memset(out, 0xA5, (size_t)n_sets * cap * 32);
+    const int rc = yp_detect_yolov3_multi(heads.data(), n_heads, n_sets, &p, out, cap, count, stats, ws, need, nullptr);
+    if (rc != 0) { std::printf("yp_detect_yolov3_multi returned %d\n", rc); return 1; }
+    int bad = 0;
+    for (int set = 0; set < n_sets; ++set) {
+        int32_t want;
+        if (!read_exact(f, &want, 4)) return 2;
+        const int n = want < cap ? want : cap;
+        std::vector<float> rows((size_t)n * 8);
+        if (!read_exact(f, rows.data(), rows.size() * 4)) return 2;
+        if (count[set] != want) { std::printf("set %d: count %d, expected %d\n", set, count[set], want); ++bad; continue; }
+        if (std::memcmp(rows.data(), out + (size_t)set * cap * 8, rows.size() * 4) != 0) {
+            std::printf("set %d: rows differ\n", set);
+            ++bad;
+        }
+        long kept = 0;
+        for (int i = 0; i < B * C; ++i) kept += stats[((size_t)set * 4 + 1) * B * C + i];
+        if (kept != want) { std::printf("set %d: statistics count %ld kept rows, expected %d\n", set, kept, want); ++bad; }
+    }
+    long st[5];
+    emul_stats(st, 0);
+    std::printf("%s: %d sets, %ld collectives, %ld divergent groups, %ld shuffles from inactive lanes, %ld workgroups\n",
+                bad ? "MISMATCH" : "ok", n_sets, st[0], st[1], st[2], st[4]);
+    return bad || st[1] || st[2] ? 1 : 0;
+}

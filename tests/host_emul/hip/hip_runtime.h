@@ -1,77 +1,399 @@
-// Host emulation of the few HIP constructs the small bookkeeping kernels use -- TEST
-// INFRASTRUCTURE ONLY.  Included in place of <hip/hip_runtime.h> when a kernel source file is
-// compiled with g++ for tests/test_v_metrics.py: a launch runs its workgroups one after another,
-// every workgroup as blockDim.x OS threads that meet at a std::barrier where the kernel calls
-// __syncthreads(), so the kernel's own statements -- indexing, atomics, barriers, float
-// arithmetic in source order (-ffp-contract=off) -- execute unchanged on the CPU.  It says nothing
-// about timing or about how the GPU schedules the same code; wave-level intrinsics are not provided.
+// Host emulation of the HIP constructs this library's kernels use -- TEST INFRASTRUCTURE ONLY.
+//
+// Included in place of <hip/hip_runtime.h> when a kernel source file is compiled with g++ for the
+// emulation tests.  The kernels' own statements then execute on the CPU: indexing, atomics, LDS
+// traffic, barriers, wave collectives and the float arithmetic in source order (-ffp-contract=off),
+// inside ordinary host memory where AddressSanitizer sees every access.
+//
+// Model.  A launch runs its workgroups one after another.  Every thread of a workgroup is a
+// fibre (ucontext) on the calling OS thread; a fibre runs until it reaches a collective -- a wave
+// intrinsic (__ballot, __shfl*, readlane, readfirstlane, wave_barrier) or __syncthreads -- and
+// parks there.  When all live fibres of a wave are parked, the wave's collective is carried out
+// and they continue; when all live fibres of the workgroup are parked at __syncthreads, the
+// barrier opens.  Fibres of one wave parked at DIFFERENT source lines are in different branches:
+// the group at the earliest line goes first, alone, with only its own lanes participating (as the
+// hardware's execution mask would have it); a shuffle that reads a non-participating lane returns
+// the caller's own value and is counted in emul::stats.
+//
+// What it is not.  Lanes of a wave do not advance in lockstep between collectives, so code that
+// relies on implicit lockstep (LDS exchange inside a wave without a wave_barrier) behaves
+// differently here -- such code is wrong on the GPU's memory model too and shows up as a failure.
+// Workgroups do not overlap, so kernels whose workgroups wait for each other cannot run.  Timing,
+// occupancy, registers, the caches and the scheduler are not modelled at all.
 #pragma once
+#include <ucontext.h>
+
 #include <algorithm>
-#include <barrier>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
-#include <thread>
+#include <functional>
 #include <vector>
 
 #define __global__
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static /* one workgroup runs at a time, its threads share the variable */
+#define __shared__ thread_local /* one workgroup at a time on one OS thread: its fibres share it */
 #define __launch_bounds__(...)
+#define __align__(n) __attribute__((aligned(n)))
+#define HIP_SYMBOL(x) x
 
 struct dim3 {
     unsigned x, y, z;
     constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
-struct alignas(16) float4 {
+struct float2 {
+    float x, y;
+};
+struct __attribute__((aligned(16))) float4 {
     float x, y, z, w;
 };
+struct __attribute__((aligned(16))) int4 {
+    int x, y, z, w;
+};
+struct __attribute__((aligned(16))) ulonglong2 {
+    unsigned long long x, y;
+};
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 
+// ------------------------------------------------------------------ host API stand-ins
 typedef int hipError_t;
 typedef void *hipStream_t;
+typedef void *hipEvent_t;
 constexpr hipError_t hipSuccess = 0;
+constexpr hipError_t hipErrorInvalidValue = 1;
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipMemsetAsync(void *p, int value, size_t n, hipStream_t)
+inline const char *hipGetErrorString(hipError_t) { return "host emulation"; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *p, int value, size_t n, hipStream_t) { std::memset(p, value, n); return hipSuccess; }
+template <class T>
+inline hipError_t hipGetSymbolAddress(void **out, T &symbol) { *out = (void *)&symbol; return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+
+// ------------------------------------------------------------------ the fibre machine
+namespace emul {
+
+enum Kind { kNone = 0, kBallot, kShuffle, kFirst, kWaveBarrier, kBlockBarrier, kYield };
+
+struct Lane {
+    ucontext_t ctx;
+    dim3 tid;
+    int index = 0, lane = 0, wave = 0;
+    bool done = false;
+    int wait = kNone;        // what the fibre is parked at
+    int site = 0;            // source line of that collective
+    uint64_t post = 0;       // value it contributes
+    int src = 0;             // lane a shuffle reads
+    uint64_t result = 0;
+};
+
+struct Stats {
+    long collectives = 0, divergent_groups = 0, shuffle_from_inactive = 0, launches = 0, blocks = 0;
+};
+
+inline Stats stats;
+inline bool trace_divergence = std::getenv("YP_EMUL_TRACE") != nullptr;
+inline Lane *cur = nullptr;
+inline dim3 g_block_idx, g_block_dim, g_grid_dim;
+inline ucontext_t sched_ctx;
+inline std::vector<Lane> lanes;
+inline std::vector<char *> stacks;
+inline const std::function<void()> *body = nullptr;
+constexpr size_t kStackBytes = 256 << 10;
+
+inline void fibre_entry()
 {
-    std::memset(p, value, n);
-    return hipSuccess;
+    (*body)();
+    cur->done = true;
+    swapcontext(&cur->ctx, &sched_ctx);
 }
 
-inline thread_local dim3 threadIdx, blockIdx;
-inline dim3 blockDim, gridDim;
-inline std::barrier<> *emul_barrier = nullptr;
-inline void __syncthreads() { emul_barrier->arrive_and_wait(); }
-
-inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
-inline int atomicMin(int *p, int v)
+// Parks the running fibre at a collective and returns its result once the scheduler has
+// carried the collective out.
+inline uint64_t park(int kind, int site, uint64_t post, int src = 0)
 {
-    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
-    while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    Lane *me = cur;
+    me->wait = kind;
+    me->site = site;
+    me->post = post;
+    me->src = src;
+    swapcontext(&me->ctx, &sched_ctx);
+    return me->result;
+}
+
+[[noreturn]] inline void die(const char *what)
+{
+    std::fprintf(stderr, "host emulation: %s (block %u,%u,%u)\n", what, g_block_idx.x, g_block_idx.y, g_block_idx.z);
+    for (const Lane &l : lanes)
+        if (!l.done) std::fprintf(stderr, "  thread %d: wait kind %d at line %d\n", l.index, l.wait, l.site / 64);
+    std::abort();
+}
+
+// Carries out what the parked fibres of one wave allow.  Returns true if any fibre was released.
+inline bool resolve_wave(int w, int n_threads)
+{
+    const int lo = w * 64, hi = std::min(n_threads, lo + 64);
+    int site = 0x7fffffff, kind = kNone;
+    for (int i = lo; i < hi; ++i) {
+        const Lane &l = lanes[i];
+        if (l.done) continue;
+        if (l.wait == kNone || l.wait == kYield) return false;  // somebody can still run
+        if (l.site < site) { site = l.site; kind = l.wait; }
     }
-    return old;
+    if (kind == kNone || kind == kBlockBarrier) return false;  // (the workgroup barrier is resolved by the caller)
+    uint64_t ballot = 0;
+    int first = -1, others = 0;
+    for (int i = lo; i < hi; ++i) {
+        const Lane &l = lanes[i];
+        if (l.done) continue;
+        if (l.site != site) { ++others; continue; }
+        if (l.wait != kind) die("two kinds of collective at one source line");
+        if (first < 0) first = i;
+        if (kind == kBallot && l.post) ballot |= 1ull << l.lane;
+    }
+    if (others) {
+        ++stats.divergent_groups;
+        if (trace_divergence) {
+            int other_site = 0;
+            for (int i = lo; i < hi; ++i)
+                if (!lanes[i].done && lanes[i].site != site) other_site = lanes[i].site;
+            std::fprintf(stderr, "host emulation: wave %d split: line %d (kind %d) goes before line %d; %d lanes wait\n",
+                         w, site / 64, kind, other_site / 64, others);
+        }
+    }
+    ++stats.collectives;
+    for (int i = lo; i < hi; ++i) {
+        Lane &l = lanes[i];
+        if (l.done || l.site != site) continue;
+        switch (kind) {
+        case kBallot: l.result = ballot; break;
+        case kFirst: l.result = lanes[first].post; break;
+        case kShuffle: {
+            const int s = lo + l.src;
+            if (l.src >= 0 && s < hi && !lanes[s].done && lanes[s].site == site && lanes[s].wait == kShuffle) {
+                l.result = lanes[s].post;
+            } else {
+                l.result = l.post;     // outside the wave: the defined result; a lane that is not taking part: undefined on the GPU
+                if (l.src >= 0 && l.src < 64) ++stats.shuffle_from_inactive;
+            }
+            break;
+        }
+        default: l.result = 0; break;
+        }
+    }
+    for (int i = lo; i < hi; ++i) {
+        Lane &l = lanes[i];
+        if (!l.done && l.site == site && l.wait == kind) l.wait = kNone, l.site = 0;
+    }
+    return true;
 }
 
-template <class Kernel, class... Args>
-void emul_launch(Kernel kernel, dim3 grid, dim3 block, Args... args)
+inline void run_block(int n_threads)
 {
-    blockDim = block;
-    gridDim = grid;
-    for (unsigned b = 0; b < grid.x; ++b) {
-        std::barrier<> bar((std::ptrdiff_t)block.x);
-        emul_barrier = &bar;
-        std::vector<std::thread> threads;
-        threads.reserve(block.x);
-        for (unsigned t = 0; t < block.x; ++t)
-            threads.emplace_back([=] {
-                threadIdx = dim3(t);
-                blockIdx = dim3(b);
-                kernel(args...);
-                emul_barrier->arrive_and_drop();   // a thread that left early no longer counts
-            });
-        for (auto &th : threads) th.join();
+    if ((int)lanes.size() < n_threads) lanes.resize(n_threads);
+    while ((int)stacks.size() < n_threads) stacks.push_back((char *)std::malloc(kStackBytes));
+    for (int i = 0; i < n_threads; ++i) {
+        Lane &l = lanes[i];
+        l.tid = dim3((unsigned)i);
+        l.index = i;
+        l.lane = i & 63;
+        l.wave = i >> 6;
+        l.done = false;
+        l.wait = kNone;
+        l.site = 0;
+        getcontext(&l.ctx);
+        l.ctx.uc_stack.ss_sp = stacks[i];
+        l.ctx.uc_stack.ss_size = kStackBytes;
+        l.ctx.uc_link = &sched_ctx;
+        makecontext(&l.ctx, fibre_entry, 0);
     }
+    const int n_waves = (n_threads + 63) / 64;
+    for (;;) {
+        bool progress = false, all_done = true;
+        for (int w = 0; w < n_waves; ++w) {
+            bool again = true;
+            while (again) {
+                again = false;
+                for (int i = w * 64; i < std::min(n_threads, w * 64 + 64); ++i) {
+                    Lane &l = lanes[i];
+                    if (l.wait == kYield) l.wait = kNone;
+                    if (l.done || l.wait != kNone) continue;
+                    cur = &l;
+                    swapcontext(&sched_ctx, &l.ctx);
+                    progress = true;
+                }
+                for (int i = w * 64; i < std::min(n_threads, w * 64 + 64); ++i)
+                    if (!lanes[i].done && lanes[i].wait == kYield) again = true;
+                if (!again && resolve_wave(w, n_threads)) again = progress = true;
+            }
+        }
+        bool at_barrier = true;
+        for (int i = 0; i < n_threads; ++i) {
+            if (lanes[i].done) continue;
+            all_done = false;
+            if (lanes[i].wait != kBlockBarrier) at_barrier = false;
+        }
+        if (all_done) break;
+        if (at_barrier) {
+            for (int i = 0; i < n_threads; ++i)
+                if (!lanes[i].done) lanes[i].wait = kNone, lanes[i].site = 0;
+            ++stats.collectives;
+            continue;
+        }
+        if (!progress) die("deadlock: no fibre can run and no collective is complete");
+    }
+    cur = nullptr;
 }
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emul_launch(kernel, grid, block, __VA_ARGS__)
+
+inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &kernel_call)
+{
+    if (block.y != 1 || block.z != 1) die("only one-dimensional workgroups are emulated");
+    if (block.x == 0 || block.x > 1024 || lds_bytes > (160u << 10)) die("launch shape beyond the hardware's");
+    if (cur != nullptr) die("launch from inside a kernel");
+    body = &kernel_call;
+    g_block_dim = block;
+    g_grid_dim = grid;
+    ++stats.launches;
+    for (unsigned z = 0; z < grid.z; ++z)
+        for (unsigned y = 0; y < grid.y; ++y)
+            for (unsigned x = 0; x < grid.x; ++x) {
+                g_block_idx = dim3(x, y, z);
+                ++stats.blocks;
+                run_block((int)block.x);
+            }
+    body = nullptr;
+}
+
+template <class T>
+inline uint64_t bits_of(T v)
+{
+    static_assert(sizeof(T) <= 8, "shuffles move at most 64 bits");
+    uint64_t b = 0;
+    std::memcpy(&b, &v, sizeof(T));
+    return b;
+}
+template <class T>
+inline T from_bits(uint64_t b)
+{
+    T v;
+    std::memcpy(&v, &b, sizeof(T));
+    return v;
+}
+template <class T>
+inline T shuffle(T v, int src, int site)
+{
+    return from_bits<T>(park(kShuffle, site, bits_of(v), src));
+}
+
+template <class T>
+inline T peek_lane(const T *mine, int l)
+{
+    // let every other fibre that can run reach its next parking place first: the lane being read
+    // may still be on its way from the last collective to the statement that sets the variable
+    park(kYield, 0, 0);
+    const Lane *me = cur;
+    const long off = reinterpret_cast<const char *>(mine) - stacks[me->index];
+    if (off < 0 || off + (long)sizeof(T) > (long)kStackBytes) die("readlane of something that is not a local variable");
+    if (l < 0 || l > 63 || me->wave * 64 + l >= (int)g_block_dim.x) die("readlane of a lane outside the wave");
+    T v;
+    std::memcpy(&v, stacks[me->wave * 64 + l] + off, sizeof(T));
+    return v;
+}
+
+template <class T>
+inline std::remove_const_t<T> read_lane(T &v, int l, int)
+{
+    return peek_lane<std::remove_const_t<T>>(&v, l);
+}
+template <class T, class = std::enable_if_t<!std::is_lvalue_reference_v<T>>>
+inline T read_lane(T &&v, int l, int site)
+{
+    return shuffle<T>(v, l, site);
+}
+
+template <class T>
+inline T first_lane(T v, int site)
+{
+    return from_bits<T>(park(kFirst, site, bits_of(v)));
+}
+
+}  // namespace emul
+
+#define threadIdx (emul::cur->tid)
+#define blockIdx (emul::g_block_idx)
+#define blockDim (emul::g_block_dim)
+#define gridDim (emul::g_grid_dim)
+
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    emul::launch(grid, block, lds, [&] { kernel(__VA_ARGS__); })
+#define hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev0, ev1, flags, ...) \
+    emul::launch(grid, block, lds, [&] { kernel(__VA_ARGS__); })
+
+// ------------------------------------------------------------------ device intrinsics
+#define EMUL_SITE (__LINE__ * 64 + (int)(sizeof(__FILE__) % 64))
+#define __syncthreads() ((void)emul::park(emul::kBlockBarrier, EMUL_SITE, 0))
+#define __threadfence_block() ((void)0)
+#define __threadfence() ((void)0)
+#define __ballot(p) ((unsigned long long)emul::park(emul::kBallot, EMUL_SITE, (p) ? 1 : 0))
+#define __any(p) (emul::park(emul::kBallot, EMUL_SITE, (p) ? 1 : 0) != 0)
+#define __shfl(v, src, ...) emul::shuffle((v), (int)(src), EMUL_SITE)
+#define __shfl_xor(v, mask, ...) emul::shuffle((v), emul::cur->lane ^ (int)(mask), EMUL_SITE)
+#define __shfl_up(v, delta, ...) emul::shuffle((v), emul::cur->lane - (int)(delta), EMUL_SITE)
+#define __shfl_down(v, delta, ...) emul::shuffle((v), emul::cur->lane + (int)(delta), EMUL_SITE)
+// v_readlane_b32 reads a lane's register whatever the execution mask says, also from inside a
+// branch the lane did not take.  Here: the same local variable in the other fibre's frame (the
+// fibres of a wave run the same function at the same stack depth, so the variable sits at the same
+// offset of every fibre's stack).  The argument therefore has to be a named local variable that the
+// lane wrote before the wave's last collective; any other expression is read as a shuffle among
+// the lanes that take part.
+#define __builtin_amdgcn_readlane(v, l) emul::read_lane((v), (int)(l), EMUL_SITE)
+#define __builtin_amdgcn_readfirstlane(v) emul::first_lane((v), EMUL_SITE)
+#define __builtin_amdgcn_wave_barrier() ((void)emul::park(emul::kWaveBarrier, EMUL_SITE, 0))
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
+
+inline unsigned emul_lanes_below(unsigned lo_or_hi_mask, bool hi)
+{
+    const int lane = emul::cur->lane;
+    unsigned below;
+    if (!hi) below = lane >= 32 ? 0xffffffffu : ((1u << lane) - 1u);
+    else below = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
+    return (unsigned)__builtin_popcount(lo_or_hi_mask & below);
+}
+#define __builtin_amdgcn_mbcnt_lo(mask, base) ((base) + emul_lanes_below((mask), false))
+#define __builtin_amdgcn_mbcnt_hi(mask, base) ((base) + emul_lanes_below((mask), true))
+
+#define __popcll(v) __builtin_popcountll(v)
+#define __popc(v) __builtin_popcount(v)
+#define __ffsll(v) __builtin_ffsll(v)
+inline unsigned __float_as_uint(float f) { return emul::from_bits<unsigned>(emul::bits_of(f)); }
+inline int __float_as_int(float f) { return emul::from_bits<int>(emul::bits_of(f)); }
+inline float __uint_as_float(unsigned u) { return emul::from_bits<float>(emul::bits_of(u)); }
+inline float __int_as_float(int i) { return emul::from_bits<float>(emul::bits_of(i)); }
+
+// Atomics: the fibres of a workgroup share one OS thread and workgroups do not overlap.
+template <class T>
+inline T atomicAdd(T *p, T v) { const T old = *p; *p = old + v; return old; }
+inline int atomicAdd(int *p, unsigned v) { const int old = *p; *p = old + (int)v; return old; }
+template <class T>
+inline T atomicMin(T *p, T v) { const T old = *p; if (v < old) *p = v; return old; }
+template <class T>
+inline T atomicMax(T *p, T v) { const T old = *p; if (v > old) *p = v; return old; }
+template <class T>
+inline T atomicOr(T *p, T v) { const T old = *p; *p = old | v; return old; }
+
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }
+
+// Single-instruction float max / min of the kernels (inline GCN assembly on the device).
+#define YP_VMAX_F32(r, a, b) ((r) = std::fmax((a), (b)))
+#define YP_VMIN_F32(r, a, b) ((r) = std::fmin((a), (b)))

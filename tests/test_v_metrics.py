@@ -137,24 +137,14 @@ def test_detection_rows_packing(pkg):
 
 
 def _emulated_library():
-    """csrc/metrics.hip compiled with g++ against tests/host_emul (workgroups as OS threads that
-    meet at a barrier where the kernel synchronises): the kernels' own source, run on the CPU."""
+    """The library's kernels compiled with g++ against tests/host_emul (every GPU thread a fibre
+    on the CPU, barriers and wave collectives as rendezvous): the kernels' own source."""
     import shutil
     import subprocess
-    gxx = shutil.which("g++")
-    if gxx is None:
-        pytest.skip("g++ is not installed here")
-    build = os.path.join(HERE, "_build")
-    os.makedirs(build, exist_ok=True)
-    so = os.path.join(build, "libmetrics_emul.so")
-    deps = [os.path.join(HERE, "host_emul", "emul_metrics.cpp"), os.path.join(HERE, "host_emul", "hip", "hip_runtime.h"),
-            os.path.join(HERE, "..", "2d_object_detection_amd", "csrc", "metrics.hip"),
-            os.path.join(HERE, "..", "include", "yolopost.h")]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in deps):
-        subprocess.check_call([gxx, "-std=c++20", "-O1", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
-                               "-I" + os.path.join(HERE, "host_emul"), "-I" + os.path.join(HERE, "..", "include"),
-                               "-o", so, deps[0]])
-    return ctypes.CDLL(so)
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("g++ / make are not installed here")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "host_emul")])
+    return ctypes.CDLL(os.path.join(HERE, "_build", "libyolopost_emul.so"))
 
 
 def _run_emulated(lib, rows, gi, gb, gc, num_classes, thr, det_cap, gt_cap):

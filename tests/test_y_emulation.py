@@ -1,0 +1,254 @@
+"""The library's kernels executed on the CPU from their own source (tests/host_emul: every GPU
+thread a fibre, wave intrinsics and barriers as rendezvous of fibres) and compared with the
+oracle bit for bit -- a check of the kernels' logic (indexing, collectives, barriers, atomics,
+float order) that needs no GPU -- and the same under AddressSanitizer + UBSan with every buffer a
+heap block of exactly its documented size.  It says nothing about timing or about how the
+hardware schedules the code; the GPU parity tests remain the proof that the library works."""
+import ctypes
+import importlib
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import np_oracle as npo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMUL = os.path.join(HERE, "host_emul")
+BUILD = os.path.join(HERE, "_build")
+
+
+def _make(target):
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("g++ / make are not installed here")
+    subprocess.check_call(["make", "-s", "-C", EMUL, os.path.join("..", "_build", target)])
+    return os.path.join(BUILD, target)
+
+
+@pytest.fixture(scope="module")
+def emu(pkg):
+    """The emulated library with the argument types of the real one."""
+    lib = ctypes.CDLL(_make("libyolopost_emul.so"))
+    real = pkg._lib.load()
+    for name in pkg._lib.EXPORTED_SYMBOLS:
+        fn, ref = getattr(lib, name), getattr(real, name)
+        fn.restype = ref.restype
+        if ref.argtypes is not None:
+            fn.argtypes = ref.argtypes
+    return lib
+
+
+def aligned(nbytes, align=256, fill=0):
+    buf = np.full(nbytes + align, fill, np.uint8)
+    off = (-buf.ctypes.data) % align
+    return buf[off:off + nbytes]
+
+
+def emul_counters(lib, reset=True):
+    a = (ctypes.c_long * 5)()
+    lib.emul_stats(a, 1 if reset else 0)
+    return dict(zip(("collectives", "divergent", "shuffle_from_inactive", "launches", "workgroups"), a))
+
+
+def head_descs(pkg, heads, inp_dim, C):
+    """YpHead descriptors over host arrays (the emulation reads host memory)."""
+    L, syn = pkg._lib, pkg.synthetic
+    in_h, in_w = (inp_dim, inp_dim) if np.isscalar(inp_dim) else inp_dim
+    out = []
+    for h, anc in zip(heads, syn.YOLOV3_ANCHORS):
+        gh, gw = h.shape[2], h.shape[3]
+        sx, sy = in_w // gw, in_h // gh
+        d = L.make_head(None, gh, gw, [tuple(a) for a in oracle.scaled_anchors(anc, sx, sy)], sx, sy)
+        d.data = h.ctypes.data
+        out.append(d)
+    return out
+
+
+def run_detect(pkg, lib, sets, inp_dim, conf, nms=0.4, C=5, dense=False, frame=None, cap=None, offset=0):
+    """yp_detect_yolov3_multi on host arrays; returns (rows per set, counts, stats)."""
+    L, util = pkg._lib, pkg.util
+    n_sets, B = len(sets), sets[0][0].shape[0]
+    flat = [d for heads in sets for d in head_descs(pkg, heads, inp_dim, C)]
+    descs = (L.YpHead * len(flat))(*flat)
+    p = util._v3_params(B, C, conf, nms, batch_offset=offset, dense=dense, frame=frame)
+    need = lib.yp_detect_yolov3_workspace_bytes(descs, 3, n_sets * B, C)
+    ws = aligned(need, fill=0xA5)
+    rows_per_image = sum(h.shape[1] // (5 + C) * h.shape[2] * h.shape[3] for h in sets[0])
+    cap = B * rows_per_image + (B * rows_per_image & 1) if cap is None else cap
+    out = aligned(n_sets * cap * 32, 16, fill=0xA5).view(np.float32).reshape(n_sets, cap, 8)
+    cnt = np.full(n_sets, -1, np.int32)
+    st = np.full((n_sets, 4, B, C), -1, np.int32)
+    rc = lib.yp_detect_yolov3_multi(descs, 3, n_sets, ctypes.byref(p), out.ctypes.data, cap, cnt.ctypes.data,
+                                    st.ctypes.data, ws.ctypes.data, need, None)
+    assert rc == 0, lib.yp_strerror(rc)
+    return out, cnt, st
+
+
+def make_sets(pkg, n_sets, B, inp_dim, seed, clustered=False):
+    syn = pkg.synthetic
+    return [[np.ascontiguousarray(h.numpy()) for h in syn.make_heads(B, inp_dim, 5, seed=seed + 17 * k, clustered=clustered)]
+            for k in range(n_sets)]
+
+
+@pytest.mark.parametrize("name,n_sets,B,inp_dim,conf,clustered,dense,frame", [
+    ("small", 1, 2, 96, 0.3, True, False, None),
+    ("cfg2 shape, 3 images", 1, 3, 416, 0.5, False, False, None),
+    ("three sets per launch", 3, 2, 96, 0.4, True, False, None),
+    ("rectangular input, rescaled to the camera frame", 1, 2, (320, 480), 0.4, False, False, (1280, 1920)),
+    ("segments of ~1500: chunked path", 1, 1, 416, 0.01, False, False, None),
+    ("segments of ~1500: graph path", 1, 1, 416, 0.01, False, True, None),
+    ("clustered segments on the graph path, two sets", 2, 1, (320, 480), 0.01, True, True, None),
+    ("graph flag set, no segment large enough", 1, 2, 96, 0.3, True, True, None),
+])
+def test_emulated_detect_matches_oracle(pkg, emu, name, n_sets, B, inp_dim, conf, clustered, dense, frame):
+    syn = pkg.synthetic
+    sets = make_sets(pkg, n_sets, B, inp_dim, 500, clustered)
+    emul_counters(emu)
+    out, cnt, st = run_detect(pkg, emu, sets, inp_dim, conf, dense=dense, frame=frame, offset=3)
+    c = emul_counters(emu)
+    assert c["launches"] == (5 if dense else 3), c     # the two graph kernels are launched only with the flag
+    assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c      # every collective was wave-uniform
+    for k, heads in enumerate(sets):
+        want, surv, _ = oracle.n_detect(heads, inp_dim, syn.YOLOV3_ANCHORS, 5, conf, 0.4)
+        if frame is not None:
+            want = npo.n_rescale(want, inp_dim, frame)
+        want = want.copy()
+        want[:, 0] += 3
+        assert cnt[k] == len(want), name
+        assert np.array_equal(out[k, :len(want)], want), name
+        assert np.array_equal(st[k, 0].sum(1), surv) and st[k, 1].sum() == len(want)
+        if "path" in name:
+            assert st[k, 0].max() > 768          # the case does exercise the large-segment code
+        # rows beyond the count were never written
+        assert (out[k, len(want):].view(np.uint8) == 0xA5).all()
+
+
+def test_emulated_capacity_overflow_and_single_entry(pkg, emu):
+    """Fewer output rows than detections: the count is the true total, the slab holds the first
+    `cap` rows, nothing is written past it; and yp_detect_yolov3 equals the multi entry with one set."""
+    L, util, syn = pkg._lib, pkg.util, pkg.synthetic
+    sets = make_sets(pkg, 2, 2, 96, 900, True)
+    full, cnt_full, _ = run_detect(pkg, emu, sets, 96, 0.3)
+    cap = (int(cnt_full.min()) // 2) & ~1
+    out, cnt, _ = run_detect(pkg, emu, sets, 96, 0.3, cap=cap)
+    assert np.array_equal(cnt, cnt_full) and cap > 0
+    for k in range(2):
+        assert np.array_equal(out[k], full[k, :cap])
+    descs = (L.YpHead * 3)(*head_descs(pkg, sets[1], 96, 5))
+    p = util._v3_params(2, 5, 0.3, 0.4)
+    need = emu.yp_detect_yolov3_workspace_bytes(descs, 3, 2, 5)
+    ws = aligned(need)
+    one = aligned(int(cnt_full[1]) * 32 + 32, 16).view(np.float32).reshape(-1, 8)
+    n = np.zeros(1, np.int32)
+    rc = emu.yp_detect_yolov3(descs, 3, ctypes.byref(p), one.ctypes.data, len(one), n.ctypes.data, None,
+                              ws.ctypes.data, need, None)
+    assert rc == 0 and n[0] == cnt_full[1] and np.array_equal(one[:n[0]], full[1, :n[0]])
+
+
+def test_emulated_write_results_on_decoded_rows(pkg, emu):
+    """The rows entry (yp_write_results) on segments above 512 and above 768 candidates, both
+    NMS paths, against the oracle on the same decoded rows."""
+    from test_gpu_parity import big_segment_rows
+    util = pkg.util
+    rows, C = big_segment_rows(1000, 7)
+    rows = np.ascontiguousarray(rows)
+    want, surv, _ = oracle.n_write_results(rows, 0.5, C, 0.05)
+    assert surv.max() > 768
+    B, N = rows.shape[0], rows.shape[1]
+    for dense in (False, True):
+        p = util._v3_params(B, C, 0.5, 0.05, dense=dense)
+        need = emu.yp_rows_workspace_bytes(B, N, C)
+        ws = aligned(need)
+        cap = B * N + (B * N & 1)
+        out = aligned(cap * 32, 16).view(np.float32).reshape(cap, 8)
+        n = np.zeros(1, np.int32)
+        rc = emu.yp_write_results(rows.ctypes.data, N, ctypes.byref(p), out.ctypes.data, cap, n.ctypes.data, None,
+                                  ws.ctypes.data, need, None)
+        assert rc == 0 and n[0] == len(want), dense
+        assert np.array_equal(out[:n[0]], want), dense
+    c = emul_counters(emu)
+    assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
+
+
+def test_emulated_reference_mode(pkg, emu):
+    """yp_detect_reference (detect_net.py:90-183 in one pass) against the oracle."""
+    L, P = pkg._lib, pkg.params
+    B, H, W, A, C, mb = 5, 13, 13, 5, 5, 20
+    pred = np.ascontiguousarray(pkg.synthetic.make_reference_head(B, seed=77, relu=True, obj_mean=0.5).numpy())
+    anc = np.asarray(P.YOLO_ANCHORS, np.float32).reshape(-1, 2)
+    head = L.make_head(None, H, W, [tuple(a) for a in anc])
+    head.data = pred.ctypes.data
+    p = L.YpParams()
+    p.mode, p.batch, p.num_classes, p.max_out = L.YP_MODE_REFERENCE, B, C, mb
+    p.conf_thr, p.nms_thr, p.im_h, p.im_w = P.object_conf, P.nms_conf, P.im_height, P.im_width
+    need = emu.yp_detect_reference_workspace_bytes(B, H, W, A)
+    ws = aligned(need)
+    boxes = aligned(B * mb * 16, 16).view(np.float32).reshape(B, mb, 4)
+    scores = np.zeros((B, mb), np.float32)
+    classes, index = np.zeros((B, mb), np.int32), np.zeros((B, mb), np.int32)
+    counts, surv = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    rc = emu.yp_detect_reference(ctypes.byref(head), ctypes.byref(p), boxes.ctypes.data, scores.ctypes.data,
+                                 classes.ctypes.data, index.ctypes.data, counts.ctypes.data, surv.ctypes.data,
+                                 ws.ctypes.data, need, None)
+    assert rc == 0
+    ob, os_, oc, oi, osurv = oracle.r_detect(pred, H, W, A, C, anc, P.object_conf, P.nms_conf, mb, P.im_height,
+                                             P.im_width)
+    assert np.array_equal(surv, osurv) and counts.sum() > 0
+    for b in range(B):
+        n = counts[b]
+        assert n == len(os_[b])
+        assert np.array_equal(boxes[b, :n], ob[b]) and np.array_equal(scores[b, :n], os_[b])
+        assert np.array_equal(classes[b, :n], oc[b]) and np.array_equal(index[b, :n], oi[b])
+    c = emul_counters(emu)
+    assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
+
+
+def write_case(path, pkg, sets, inp_dim, conf, C, flags, cap, frame, expected):
+    n_sets, B = len(sets), sets[0][0].shape[0]
+    descs = head_descs(pkg, sets[0], inp_dim, C)
+    im_h, im_w = (0.0, 0.0) if frame is None else frame
+    with open(path, "wb") as f:
+        f.write(struct.pack("<8i4f", 0x31455059, n_sets, B, C, len(descs), flags, cap, 0, conf, 0.4, im_h, im_w))
+        for d in descs:
+            f.write(struct.pack("<3i2f16f", d.grid_h, d.grid_w, d.num_anchors, d.stride_x, d.stride_y, *d.anchors))
+        for heads in sets:
+            for h in heads:
+                f.write(np.ascontiguousarray(h, np.float32).tobytes())
+        for want in expected:
+            f.write(struct.pack("<i", len(want)))
+            f.write(np.ascontiguousarray(want[:cap], np.float32).tobytes())
+
+
+def test_emulated_kernels_under_address_and_ub_sanitizers(pkg, tmp_path):
+    """The same kernels, built with -fsanitize=address,undefined, replaying recorded calls whose
+    buffers are heap blocks of exactly the documented sizes: small segments, the chunked
+    large-segment path, the graph path, several sets with a capacity smaller than the output,
+    and the rescale.  The sanitizers must stay silent and the rows must equal the oracle's."""
+    syn, L = pkg.synthetic, pkg._lib
+    exe = _make("emul_driver_asan")
+    cases = [
+        ("small", 1, 2, 96, 0.3, True, 0, None, 1.0),
+        ("chunked", 1, 1, 416, 0.01, False, 0, None, 1.0),
+        ("graph", 1, 1, 416, 0.01, False, L.YP_FLAG_DENSE_NMS, None, 1.0),
+        ("overflow", 3, 2, 96, 0.3, True, 0, None, 0.5),
+        ("graph overflow rescale", 1, 1, (320, 480), 0.01, True, L.YP_FLAG_DENSE_NMS | L.YP_FLAG_RESCALE,
+         (1280.0, 1920.0), 0.3),
+    ]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0")
+    for name, n_sets, B, inp_dim, conf, clustered, flags, frame, cap_frac in cases:
+        sets = make_sets(pkg, n_sets, B, inp_dim, 300, clustered)
+        expected = []
+        for heads in sets:
+            want, _, _ = oracle.n_detect(heads, inp_dim, syn.YOLOV3_ANCHORS, 5, conf, 0.4)
+            expected.append(npo.n_rescale(want, inp_dim, frame) if frame is not None else want)
+        cap = max(2, int(max(len(w) for w in expected) * cap_frac) + 2 & ~1)
+        path = str(tmp_path / "case.bin")
+        write_case(path, pkg, sets, inp_dim, conf, 5, flags, cap, frame, expected)
+        out = subprocess.run([exe, path], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, (name, out.stdout[-1500:], out.stderr[-3000:])
+        assert out.stdout.strip().splitlines()[-1].startswith("ok"), (name, out.stdout[-500:])
+        assert "Sanitizer" not in out.stderr and "runtime error" not in out.stderr, (name, out.stderr[-3000:])
