@@ -871,6 +871,100 @@ __device__ __forceinline__ void bitonic_sort_wide(KeyPtr keys, int n_pad)
     __syncthreads();
 }
 
+// Stages k_first..k_last of the ascending bitonic network on ONE block of kSegThreads * E keys
+// that sits in LDS and holds positions base .. base + kSegThreads*E - 1 of a longer sequence
+// (base a multiple of the block size): the passes whose partner distance is below the block size,
+// with the keys in registers as in bitonic_sort_wide.  The direction of a compare-exchange is
+// that of the whole sequence's network, (position & k) == 0 -> ascending.
+template <int E, class KeyPtr>
+__device__ __forceinline__ void bitonic_block_wide(KeyPtr keys, int base, int k_first, int k_last)
+{
+    constexpr int NL = kSegThreads * E;
+    const int t = threadIdx.x, lane = t & 63;
+    u64 v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) v[r] = keys[t * E + r];
+    for (int k = k_first; k <= k_last; k <<= 1) {
+        for (int j = (k >> 1) < (NL >> 1) ? (k >> 1) : (NL >> 1); j > 0; j >>= 1) {
+            if (j >= 64 * E) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) keys[t * E + r] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const int idx = t * E + r;
+                    const u64 y = keys[idx ^ j];
+                    const bool keep_min = ((idx & j) == 0) == (((base + idx) & k) == 0);
+                    v[r] = (keep_min == (v[r] < y)) ? v[r] : y;
+                }
+                __syncthreads();
+            } else if (j >= E) {
+                const int dl = j / E;   // partner lane = lane ^ dl, same register index
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const int idx = t * E + r;
+                    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v[r], dl, 64);
+                    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v[r] >> 32), dl, 64);
+                    const u64 y = ((u64)hi << 32) | lo;
+                    const bool keep_min = ((lane & dl) == 0) == (((base + idx) & k) == 0);
+                    v[r] = (keep_min == (v[r] < y)) ? v[r] : y;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    if ((r & j) == 0) {   // (j < E: both of the pair are this thread's)
+                        const int idx = t * E + r;
+                        const u64 a = v[r], b = v[r | j];
+                        const bool up = ((base + idx) & k) == 0;
+                        const bool swap = (a > b) == up;
+                        v[r] = swap ? b : a;
+                        v[r | j] = swap ? a : b;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < E; ++r) keys[t * E + r] = v[r];
+    __syncthreads();
+}
+
+// Ascending bitonic sort of n_pad > kBigSortCap keys (a power of two) that live in global memory,
+// by one workgroup: only the passes whose partner distance reaches the LDS block (kBigSortCap
+// keys) go through global memory -- log2(n_pad / block) * (that + 1) / 2 of them, 6 for 32 768
+// keys instead of 120 --, everything below is done block by block inside LDS.
+__device__ __forceinline__ void bitonic_sort_blocked(u64 *g, u64 *lds, int n_pad)
+{
+    constexpr int BLK = kBigSortCap, E = kBigSortCap / kSegThreads;
+    static_assert(E * kSegThreads == kBigSortCap && (E & (E - 1)) == 0, "a block is E keys per thread");
+    const int tid = threadIdx.x;
+    auto block_stages = [&](int base, int k_first, int k_last) {
+        for (int i = tid; i < BLK; i += kSegThreads) lds[i] = g[base + i];
+        __syncthreads();
+        bitonic_block_wide<E>(lds, base, k_first, k_last);
+        for (int i = tid; i < BLK; i += kSegThreads) g[base + i] = lds[i];
+        __syncthreads();
+    };
+    for (int base = 0; base < n_pad; base += BLK) block_stages(base, 2, BLK);   // sorted blocks, alternating direction
+    const int half = n_pad >> 1;
+    for (int k = 2 * BLK; k <= n_pad; k <<= 1) {
+        for (int j = k >> 1; j >= BLK; j >>= 1) {
+            for (int t = tid; t < half; t += kSegThreads) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const u64 x = g[i], y = g[l];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) {
+                    g[i] = y;
+                    g[l] = x;
+                }
+            }
+            __syncthreads();
+        }
+        for (int base = 0; base < n_pad; base += BLK) block_stages(base, k, k);
+    }
+}
+
 // Rank sort of K <= kSmallCap distinct keys: element e counts the keys below it and lands
 // at that position.  `in` is padded with ~0 up to a multiple of 8 keys.  When K is small,
 // S = 2^k threads share one element (each counts a slice of the keys, combined with
@@ -1690,7 +1784,7 @@ void k_segment_nms(SegArgs s)
             for (int i = tid; i < n_pad; i += kSegThreads) keys_in[i] = gdst[i];
             __syncthreads();
             bitonic_sort(keys_in, n_pad);
-        } else bitonic_sort(gdst, n_pad);
+        } else bitonic_sort_blocked(gdst, keys_in, n_pad);
         STAMP(3);
         float4 *gbox = s.sbox + reg;
         int *gslot = s.sslot + reg;

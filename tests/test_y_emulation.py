@@ -103,6 +103,7 @@ def make_sets(pkg, n_sets, B, inp_dim, seed, clustered=False):
     ("segments of ~1500: graph path", 1, 1, 416, 0.01, False, True, None),
     ("clustered segments on the graph path, two sets", 2, 1, (320, 480), 0.01, True, True, None),
     ("graph flag set, no segment large enough", 1, 2, 96, 0.3, True, True, None),
+    ("segments of ~7400: LDS-blocked sort in global memory, graph path", 1, 1, (640, 960), 0.001, False, True, None),
 ])
 def test_emulated_detect_matches_oracle(pkg, emu, name, n_sets, B, inp_dim, conf, clustered, dense, frame):
     syn = pkg.synthetic
