@@ -254,6 +254,22 @@ inline void run_block(int n_threads)
     cur = nullptr;
 }
 
+inline const int block_order = [] {
+    const char *e = std::getenv("YP_EMUL_ORDER");
+    return !e ? 0 : (std::strcmp(e, "reverse") == 0 ? 1 : (std::strcmp(e, "shuffle") == 0 ? 2 : 0));
+}();
+
+// A permutation of 0..n-1: multiplication by an odd constant modulo the next power of two,
+// walked until it lands inside the range (cycle walking).
+inline unsigned long scrambled(unsigned long i, unsigned long n)
+{
+    unsigned long m = 1;
+    while (m < n) m <<= 1;
+    unsigned long v = i;
+    do v = (v * 2654435761ul + 40503ul) & (m - 1); while (v >= n);
+    return v;
+}
+
 inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &kernel_call)
 {
     if (block.y != 1 || block.z != 1) die("only one-dimensional workgroups are emulated");
@@ -263,13 +279,17 @@ inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<
     g_block_dim = block;
     g_grid_dim = grid;
     ++stats.launches;
-    for (unsigned z = 0; z < grid.z; ++z)
-        for (unsigned y = 0; y < grid.y; ++y)
-            for (unsigned x = 0; x < grid.x; ++x) {
-                g_block_idx = dim3(x, y, z);
-                ++stats.blocks;
-                run_block((int)block.x);
-            }
+    // Workgroups of a launch may run in any order on the GPU: YP_EMUL_ORDER=reverse runs them last
+    // to first, =shuffle in a scrambled order, to show that a result does not lean on the order.
+    const unsigned long n_blocks = (unsigned long)grid.x * grid.y * grid.z;
+    for (unsigned long n = 0; n < n_blocks; ++n) {
+        unsigned long b = n;
+        if (block_order == 1) b = n_blocks - 1 - n;
+        if (block_order == 2) b = scrambled(n, n_blocks);
+        g_block_idx = dim3((unsigned)(b % grid.x), (unsigned)(b / grid.x % grid.y), (unsigned)(b / grid.x / grid.y));
+        ++stats.blocks;
+        run_block((int)block.x);
+    }
     body = nullptr;
 }
 

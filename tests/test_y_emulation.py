@@ -228,7 +228,8 @@ def test_emulated_kernels_under_address_and_ub_sanitizers(pkg, tmp_path):
     """The same kernels, built with -fsanitize=address,undefined, replaying recorded calls whose
     buffers are heap blocks of exactly the documented sizes: small segments, the chunked
     large-segment path, the graph path, several sets with a capacity smaller than the output,
-    and the rescale.  The sanitizers must stay silent and the rows must equal the oracle's."""
+    and the rescale.  The sanitizers must stay silent and the rows must equal the oracle's, also when
+    the workgroups of every launch run in another order."""
     syn, L = pkg.synthetic, pkg._lib
     exe = _make("emul_driver_asan")
     cases = [
@@ -249,7 +250,11 @@ def test_emulated_kernels_under_address_and_ub_sanitizers(pkg, tmp_path):
         cap = max(2, int(max(len(w) for w in expected) * cap_frac) + 2 & ~1)
         path = str(tmp_path / "case.bin")
         write_case(path, pkg, sets, inp_dim, conf, 5, flags, cap, frame, expected)
-        out = subprocess.run([exe, path], capture_output=True, text=True, timeout=600, env=env)
-        assert out.returncode == 0, (name, out.stdout[-1500:], out.stderr[-3000:])
-        assert out.stdout.strip().splitlines()[-1].startswith("ok"), (name, out.stdout[-500:])
-        assert "Sanitizer" not in out.stderr and "runtime error" not in out.stderr, (name, out.stderr[-3000:])
+        # workgroups of a launch run in any order on the GPU: the graph path (atomics between
+        # workgroups) is replayed with the workgroups last to first and in a scrambled order as well
+        for order in (("", "reverse", "shuffle") if name == "graph" else ("",)):
+            out = subprocess.run([exe, path], capture_output=True, text=True, timeout=600,
+                                 env=dict(env, YP_EMUL_ORDER=order))
+            assert out.returncode == 0, (name, order, out.stdout[-1500:], out.stderr[-3000:])
+            assert out.stdout.strip().splitlines()[-1].startswith("ok"), (name, order, out.stdout[-500:])
+            assert "Sanitizer:" not in out.stderr and "runtime error" not in out.stderr, (name, order, out.stderr[-3000:])
