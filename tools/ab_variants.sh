@@ -1,0 +1,36 @@
+# A/B of compile-time variants of the large-segment NMS kernels on the GPU box.  Build the
+# variants HERE first (on the CPU, before the gpurun call):
+#     bash tools/ab_variants.sh build
+# then on the GPU box (one call):
+#     bash tools/ab_variants.sh run
+# Every variant is first checked against the oracle (dense-path parity tests) and only then
+# timed; the script stops at the first failing step, so a variant that faults never gets a second
+# launch.  Results: gpurun_out/ab_variants.txt (the HEAD of every log is kept as well).
+set -e
+VARIANTS="base: t64w4:-DYP_GRAPH_TILE=64_-DYP_GRAPH_WPE=4 t128w4:-DYP_GRAPH_TILE=128_-DYP_GRAPH_WPE=4"
+CSRC=2d_object_detection_amd/csrc
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function -Iinclude -I$CSRC"
+if [ "$1" = "build" ]; then
+  for v in $VARIANTS; do
+    name=${v%%:*}; defs=$(echo "${v#*:}" | tr '_' ' ')
+    /opt/rocm/bin/hipcc $FLAGS $defs -shared -o 2d_object_detection_amd/libyolopost_$name.so \
+        $CSRC/yolopost.hip $CSRC/gridcodec.hip $CSRC/decode_grad.hip $CSRC/metrics.hip
+    /opt/rocm/bin/hipcc $FLAGS $defs -S --cuda-device-only -Rpass-analysis=kernel-resource-usage -o /dev/null $CSRC/yolopost.hip 2>&1 |
+        grep -A12 "k_graph_pairs" | grep -E "VGPRs:|ScratchSize|Occupancy" | sed "s/.*remark: [^ ]* */  $name: /; s/ \[-Rpass.*//"
+  done
+  exit 0
+fi
+OUT=gpurun_out/ab_variants.txt
+: > $OUT
+for v in $VARIANTS; do
+  name=${v%%:*}
+  export YOLOPOST_LIB=$PWD/2d_object_detection_amd/libyolopost_$name.so
+  echo "== $name" | tee -a $OUT
+  timeout -k 10 600 python -u -m pytest tests/test_u_dense_nms.py -x -q -m gpu --timeout 200 --timeout-method thread \
+      -k "rows_match or from_heads" > gpurun_out/ab_$name.parity.log 2>&1 || { head -n 40 gpurun_out/ab_$name.parity.log; echo "$name: parity FAILED, stopping" | tee -a $OUT; exit 1; }
+  tail -n 1 gpurun_out/ab_$name.parity.log | tee -a $OUT
+  CONF=0.001 timeout -k 10 120 python3 tools/nms_breakdown.py >> $OUT 2>gpurun_out/ab_$name.err || { head -n 40 gpurun_out/ab_$name.err; exit 1; }
+  DENSE=1 CONF=0.5 timeout -k 10 120 python3 tools/nms_breakdown.py >> $OUT 2>>gpurun_out/ab_$name.err || { head -n 40 gpurun_out/ab_$name.err; exit 1; }
+  DENSE=1 CONF=0.5 CLUSTERED=1 timeout -k 10 120 python3 tools/nms_breakdown.py >> $OUT 2>>gpurun_out/ab_$name.err || { head -n 40 gpurun_out/ab_$name.err; exit 1; }
+done
+cat $OUT

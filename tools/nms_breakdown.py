@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: HIP-event time of every kernel of the path (front, segment NMS, row gather, graph
-pair tests, graph resolve), one batch at a time.  B / INP / CONF / CLUSTERED from the environment."""
+pair tests, graph resolve), one batch at a time.  B / INP / CONF / CLUSTERED / DENSE (0 or 1: force the
+large-segment path off or on) from the environment."""
 import importlib
 import os
 import sys
@@ -18,7 +19,8 @@ dev = torch.device("cuda:0")
 chunks = [syn.make_heads(min(16, B - lo), inp, 5, seed=2000 + lo, clustered=bool(int(os.environ.get("CLUSTERED", "0"))))
           for lo in range(0, B, 16)]
 heads = [torch.cat([c[h] for c in chunks], 0).contiguous().to(dev) for h in range(3)]
-eng = util.YoloV3Post(B, inp, 5, conf, 0.4, device=dev)
+dense = None if "DENSE" not in os.environ else bool(int(os.environ["DENSE"]))      # default: the engine decides
+eng = util.YoloV3Post(B, inp, 5, conf, 0.4, device=dev, dense_nms=dense)
 for _ in range(3):
     eng.run(heads)
 torch.cuda.synchronize()
@@ -28,6 +30,6 @@ for _ in range(n):
     eng.run(heads)
 ms, calls = _lib.profile_stop_ex()
 surv, kept, pairs = eng.segment_stats()
-print("B=%d inp=%s conf=%g: front %.1f  nms %.1f  gather %.1f  graph_pairs %.1f  graph_resolve %.1f us; "
+print("B=%d inp=%s conf=%g dense=%s: front %.1f  nms %.1f  gather %.1f  graph_pairs %.1f  graph_resolve %.1f us; "
       "survivors/segment mean %.0f max %d, kept %d, pairs %.3g"
-      % (B, inp, conf, *(1e3 * v for v in ms), surv.mean(), surv.max(), kept.sum(), float(pairs.astype('int64').sum())))
+      % (B, inp, conf, eng.dense_nms, *(1e3 * v for v in ms), surv.mean(), surv.max(), kept.sum(), float(pairs.astype('int64').sum())))
