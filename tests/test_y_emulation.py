@@ -258,3 +258,89 @@ def test_emulated_kernels_under_address_and_ub_sanitizers(pkg, tmp_path):
             assert out.returncode == 0, (name, order, out.stdout[-1500:], out.stderr[-3000:])
             assert out.stdout.strip().splitlines()[-1].startswith("ok"), (name, order, out.stdout[-500:])
             assert "Sanitizer:" not in out.stderr and "runtime error" not in out.stderr, (name, order, out.stderr[-3000:])
+
+
+def test_emulated_grid_codec_matches_golden(pkg, emu):
+    """yp_encode_true_box_grid / yp_decode_true_box_grid (create_dataset.py:47-115, :294-328) from
+    their kernel source on the CPU against the committed vectors."""
+    from test_grid_codec import ANCHORS, golden, split_labels, ulp_diff
+    g = golden()
+    labels = split_labels(g)
+    B, H, W, A = len(labels), 13, 13, 5
+    rows = np.ascontiguousarray(np.concatenate(labels).astype(np.float64))
+    off = np.ascontiguousarray(g["label_offsets"].astype(np.int32))
+    anc = np.ascontiguousarray(ANCHORS.astype(np.float32))
+    fp = anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    grid = np.full((B, H, W, A, 5), 7.0, np.float32)
+    mask = np.full((B, H, W, A, 2), 7.0, np.float32)
+    rc = emu.yp_encode_true_box_grid(rows.ctypes.data, off.ctypes.data, B, H, W, A, fp, 1280, 1920,
+                                     grid.ctypes.data, mask.ctypes.data, None)
+    assert rc == 0
+    assert np.array_equal(mask, g["mask"]) and np.array_equal(grid[..., [0, 1, 4]], g["grid"][..., [0, 1, 4]])
+    assert ulp_diff(grid[..., 2:4], g["grid"][..., 2:4]).max() <= 1     # a binary64 log sits in between
+    cap = B * H * W * A
+    index = np.zeros((cap, 4), np.int32)
+    boxes = aligned(cap * 16, 16).view(np.float32).reshape(cap, 4)
+    cls = np.zeros(cap, np.float32)
+    n = np.zeros(1, np.int32)
+    need = emu.yp_true_box_grid_workspace_bytes(B, H, W, A)
+    ws = aligned(need, fill=0xA5)
+    gold = np.ascontiguousarray(g["grid"].astype(np.float32))
+    rc = emu.yp_decode_true_box_grid(gold.ctypes.data, B, H, W, A, fp, 1280, 1920, index.ctypes.data,
+                                     boxes.ctypes.data, cls.ctypes.data, cap, n.ctypes.data, ws.ctypes.data, need, None)
+    assert rc == 0 and n[0] == len(g["locations"])
+    assert np.array_equal(index[:n[0]], g["locations"]) and np.array_equal(boxes[:n[0]], g["boxes"])
+    c = emul_counters(emu)
+    assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
+
+
+def test_emulated_decode_and_loss_kernels(pkg, emu):
+    """predict_transform (detect_net.py:152-183), its backward and the fused loss_custom
+    (train.py:123-197) from their kernel source on the CPU: the decode bit-exact against the C
+    oracle, loss and gradients against the PyTorch restatement differentiated by autograd."""
+    import torch
+    from oracle import torch_ref
+    from test_train_grad import ANCHORS, A, C, H, W, close, make_case
+    pred, grid = make_case(3, 31)
+    B = pred.shape[0]
+    pred = np.ascontiguousarray(pred.reshape(B, -1))
+    anc = np.ascontiguousarray(np.asarray(ANCHORS, np.float32).reshape(A, 2))
+    fp = anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    center = np.zeros((B, H, W, A, 2), np.float32)
+    wh = np.zeros((B, H, W, A, 2), np.float32)
+    obj = np.zeros((B, H, W, A, 1), np.float32)
+    cls = np.zeros((B, H, W, A, C), np.float32)
+    rc = emu.yp_predict_transform_reference(pred.ctypes.data, B, H, W, A, C, fp, center.ctypes.data, wh.ctypes.data,
+                                            obj.ctypes.data, cls.ctypes.data, None)
+    assert rc == 0
+    want = oracle.r_predict_transform(pred, H, W, A, C, anc)
+    for got, w in zip((center, wh, obj, cls), want):
+        assert np.array_equal(got, w)
+    # fused loss + gradient
+    tg = np.ascontiguousarray(grid.astype(np.float32))
+    loss = np.zeros(4, np.float32)
+    gpred = np.zeros_like(pred)
+    need = emu.yp_loss_custom_reference_workspace_bytes(B, H, W, A)
+    ws = aligned(need, fill=0xA5)
+    rc = emu.yp_loss_custom_reference(pred.ctypes.data, tg.ctypes.data, B, H, W, A, C, fp, 5.0, 5.0, 1.0, 0.6,
+                                      loss.ctypes.data, gpred.ctypes.data, ws.ctypes.data, need, None)
+    assert rc == 0
+    p = torch.tensor(pred, requires_grad=True)
+    ref = torch_ref.loss_custom(p, torch.tensor(tg), H, W, A, C, ANCHORS, coord_w=5.0, obj_w=5.0, noobj_w=1.0)
+    ref[0].backward()
+    for k in range(4):      # total, confidence, classification, coordinates
+        assert abs(float(loss[k]) - float(ref[k].detach())) <= 2e-5 * abs(float(ref[k].detach())), k
+    close(gpred, p.grad.numpy())
+    # backward of the decode with random upstream gradients
+    rs = np.random.RandomState(3)
+    ups = [np.ascontiguousarray(rs.standard_normal(a.shape).astype(np.float32)) for a in (center, wh, obj, cls)]
+    gback = np.zeros_like(pred)
+    rc = emu.yp_predict_transform_reference_backward(pred.ctypes.data, B, H, W, A, C, fp, *[u.ctypes.data for u in ups],
+                                                     gback.ctypes.data, None)
+    assert rc == 0
+    p2 = torch.tensor(pred, requires_grad=True)
+    outs = torch_ref.predict_transform(p2, H, W, A, C, ANCHORS)
+    sum((o * torch.tensor(u)).sum() for o, u in zip(outs, ups)).backward()
+    close(gback, p2.grad.numpy())
+    c = emul_counters(emu)
+    assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
