@@ -21,7 +21,7 @@ out[cfg] = {
     "fetch_bytes_corrected": int(2 * fetch * 1024), "write_bytes": int(write * 1024),
     "traffic_bytes": int(2 * fetch * 1024 + write * 1024),
     "note": "per launch; FETCH_SIZE doubled (gfx950 tallies the 128-B requests of a coalesced stream "
-            "at 64 B; calibrated in round 1 on a 387 MB input where 2*FETCH matched the input bytes to "
+            "at 64 B; calibrated on a 387 MB input (profiles/r01_front_kernel_traffic.json) where 2*FETCH matched the input bytes to "
             "0.03%); separate rocprofv3 --pmc passes of `python3 bench.py --no-cpu-baseline --steps 20 "
             "--warmup 2` (tools/profile_round.sh)",
 }
