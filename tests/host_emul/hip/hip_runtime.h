@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <type_traits>
 #include <vector>
 
 #define __global__
@@ -80,6 +81,28 @@ inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 
 // ------------------------------------------------------------------ the fibre machine
+// Under ThreadSanitizer every fibre is announced to the sanitizer, and every rendezvous is a
+// release by all participants followed by an acquire: two threads of a workgroup that touch the
+// same LDS or global address, one of them writing, with no barrier or wave collective in between are
+// then reported as a data race -- although the fibres run one at a time and the result here may
+// well be right.  (Consecutive workgroups and launches are chained by the same means: races BETWEEN
+// workgroups are not looked for.)
+#if defined(__SANITIZE_THREAD__)
+extern "C" {
+void *__tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void *fiber);
+void __tsan_switch_to_fiber(void *fiber, unsigned flags);   /* flags 1: the switch itself is no synchronisation */
+void *__tsan_get_current_fiber(void);
+void __tsan_acquire(void *addr);
+void __tsan_release(void *addr);
+}
+#define EMUL_TSAN(...) __VA_ARGS__
+#define EMUL_OWN __attribute__((no_sanitize("thread")))   /* the machine's own bookkeeping is not kernel code */
+#else
+#define EMUL_TSAN(...)
+#define EMUL_OWN
+#endif
+
 namespace emul {
 
 enum Kind { kNone = 0, kBallot, kShuffle, kFirst, kWaveBarrier, kBlockBarrier, kYield };
@@ -94,6 +117,7 @@ struct Lane {
     uint64_t post = 0;       // value it contributes
     int src = 0;             // lane a shuffle reads
     uint64_t result = 0;
+    void *fiber = nullptr;   // ThreadSanitizer's handle
 };
 
 struct Stats {
@@ -109,28 +133,43 @@ inline std::vector<Lane> lanes;
 inline std::vector<char *> stacks;
 inline const std::function<void()> *body = nullptr;
 constexpr size_t kStackBytes = 256 << 10;
-
-inline void fibre_entry()
+inline void *sched_fiber = nullptr;
+inline char wave_token[16], block_token, begin_token, end_token;     // addresses the sanitizer hangs its clocks on
+// (YP_EMUL_TSAN_SELFTEST=1 hides the workgroup barriers from the sanitizer -- every kernel that needs
+// its barriers must then be reported: the check that the race detection is alive)
+inline const bool tsan_selftest = std::getenv("YP_EMUL_TSAN_SELFTEST") != nullptr;
+inline char dummy_token[1024];
+inline void *token_of(int kind, int wave)
 {
+    if (kind == kBlockBarrier) return tsan_selftest ? (void *)&dummy_token[cur->index & 1023] : (void *)&block_token;
+    return (void *)&wave_token[wave & 15];
+}
+
+EMUL_OWN inline void fibre_entry()
+{
+    EMUL_TSAN(__tsan_acquire(&begin_token);)      // what the host and earlier workgroups did comes first
     (*body)();
     cur->done = true;
+    EMUL_TSAN(__tsan_release(&end_token); __tsan_switch_to_fiber(sched_fiber, 1);)
     swapcontext(&cur->ctx, &sched_ctx);
 }
 
 // Parks the running fibre at a collective and returns its result once the scheduler has
 // carried the collective out.
-inline uint64_t park(int kind, int site, uint64_t post, int src = 0)
+EMUL_OWN inline uint64_t park(int kind, int site, uint64_t post, int src = 0)
 {
     Lane *me = cur;
     me->wait = kind;
     me->site = site;
     me->post = post;
     me->src = src;
+    EMUL_TSAN(__tsan_release(token_of(kind, me->wave)); __tsan_switch_to_fiber(sched_fiber, 1);)
     swapcontext(&me->ctx, &sched_ctx);
+    EMUL_TSAN(__tsan_acquire(token_of(kind, me->wave));)
     return me->result;
 }
 
-[[noreturn]] inline void die(const char *what)
+EMUL_OWN [[noreturn]] inline void die(const char *what)
 {
     std::fprintf(stderr, "host emulation: %s (block %u,%u,%u)\n", what, g_block_idx.x, g_block_idx.y, g_block_idx.z);
     for (const Lane &l : lanes)
@@ -139,7 +178,7 @@ inline uint64_t park(int kind, int site, uint64_t post, int src = 0)
 }
 
 // Carries out what the parked fibres of one wave allow.  Returns true if any fibre was released.
-inline bool resolve_wave(int w, int n_threads)
+EMUL_OWN inline bool resolve_wave(int w, int n_threads)
 {
     const int lo = w * 64, hi = std::min(n_threads, lo + 64);
     int site = 0x7fffffff, kind = kNone;
@@ -197,7 +236,7 @@ inline bool resolve_wave(int w, int n_threads)
     return true;
 }
 
-inline void run_block(int n_threads)
+EMUL_OWN inline void run_block(int n_threads)
 {
     if ((int)lanes.size() < n_threads) lanes.resize(n_threads);
     while ((int)stacks.size() < n_threads) stacks.push_back((char *)std::malloc(kStackBytes));
@@ -215,7 +254,9 @@ inline void run_block(int n_threads)
         l.ctx.uc_stack.ss_size = kStackBytes;
         l.ctx.uc_link = &sched_ctx;
         makecontext(&l.ctx, fibre_entry, 0);
+        EMUL_TSAN(l.fiber = __tsan_create_fiber(0);)
     }
+    EMUL_TSAN(sched_fiber = __tsan_get_current_fiber(); __tsan_release(&begin_token);)
     const int n_waves = (n_threads + 63) / 64;
     for (;;) {
         bool progress = false, all_done = true;
@@ -228,6 +269,7 @@ inline void run_block(int n_threads)
                     if (l.wait == kYield) l.wait = kNone;
                     if (l.done || l.wait != kNone) continue;
                     cur = &l;
+                    EMUL_TSAN(__tsan_switch_to_fiber(l.fiber, 1);)
                     swapcontext(&sched_ctx, &l.ctx);
                     progress = true;
                 }
@@ -252,6 +294,7 @@ inline void run_block(int n_threads)
         if (!progress) die("deadlock: no fibre can run and no collective is complete");
     }
     cur = nullptr;
+    EMUL_TSAN(__tsan_acquire(&end_token); for (int i = 0; i < n_threads; ++i) __tsan_destroy_fiber(lanes[i].fiber);)
 }
 
 inline const int block_order = [] {
@@ -261,7 +304,7 @@ inline const int block_order = [] {
 
 // A permutation of 0..n-1: multiplication by an odd constant modulo the next power of two,
 // walked until it lands inside the range (cycle walking).
-inline unsigned long scrambled(unsigned long i, unsigned long n)
+EMUL_OWN inline unsigned long scrambled(unsigned long i, unsigned long n)
 {
     unsigned long m = 1;
     while (m < n) m <<= 1;
@@ -270,7 +313,7 @@ inline unsigned long scrambled(unsigned long i, unsigned long n)
     return v;
 }
 
-inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &kernel_call)
+EMUL_OWN inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &kernel_call)
 {
     if (block.y != 1 || block.z != 1) die("only one-dimensional workgroups are emulated");
     if (block.x == 0 || block.x > 1024 || lds_bytes > (160u << 10)) die("launch shape beyond the hardware's");
@@ -309,13 +352,13 @@ inline T from_bits(uint64_t b)
     return v;
 }
 template <class T>
-inline T shuffle(T v, int src, int site)
+EMUL_OWN inline T shuffle(T v, int src, int site)
 {
     return from_bits<T>(park(kShuffle, site, bits_of(v), src));
 }
 
 template <class T>
-inline T peek_lane(const T *mine, int l)
+EMUL_OWN inline T peek_lane(const T *mine, int l)
 {
     // let every other fibre that can run reach its next parking place first: the lane being read
     // may still be on its way from the last collective to the statement that sets the variable
@@ -341,7 +384,7 @@ inline T read_lane(T &&v, int l, int site)
 }
 
 template <class T>
-inline T first_lane(T v, int site)
+EMUL_OWN inline T first_lane(T v, int site)
 {
     return from_bits<T>(park(kFirst, site, bits_of(v)));
 }
@@ -381,7 +424,7 @@ inline T first_lane(T v, int site)
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 
-inline unsigned emul_lanes_below(unsigned lo_or_hi_mask, bool hi)
+EMUL_OWN inline unsigned emul_lanes_below(unsigned lo_or_hi_mask, bool hi)
 {
     const int lane = emul::cur->lane;
     unsigned below;
@@ -400,16 +443,34 @@ inline int __float_as_int(float f) { return emul::from_bits<int>(emul::bits_of(f
 inline float __uint_as_float(unsigned u) { return emul::from_bits<float>(emul::bits_of(u)); }
 inline float __int_as_float(int i) { return emul::from_bits<float>(emul::bits_of(i)); }
 
-// Atomics: the fibres of a workgroup share one OS thread and workgroups do not overlap.
+// Atomics: the fibres of a workgroup share one OS thread and workgroups do not overlap, so any
+// read-modify-write is atomic here; integers go through the compiler's atomic builtins all the same
+// so that ThreadSanitizer (emul_driver_tsan) knows them for what they are.
 template <class T>
-inline T atomicAdd(T *p, T v) { const T old = *p; *p = old + v; return old; }
-inline int atomicAdd(int *p, unsigned v) { const int old = *p; *p = old + (int)v; return old; }
+inline T atomicAdd(T *p, T v)
+{
+    if constexpr (std::is_integral_v<T>) return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+    else { const T old = *p; *p = old + v; return old; }
+}
+inline int atomicAdd(int *p, unsigned v) { return __atomic_fetch_add(p, (int)v, __ATOMIC_RELAXED); }
 template <class T>
-inline T atomicMin(T *p, T v) { const T old = *p; if (v < old) *p = v; return old; }
+inline T atomicMin(T *p, T v)
+{
+    T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return old;
+}
 template <class T>
-inline T atomicMax(T *p, T v) { const T old = *p; if (v > old) *p = v; return old; }
+inline T atomicMax(T *p, T v)
+{
+    T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return old;
+}
 template <class T>
-inline T atomicOr(T *p, T v) { const T old = *p; *p = old | v; return old; }
+inline T atomicOr(T *p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }

@@ -344,3 +344,30 @@ def test_emulated_decode_and_loss_kernels(pkg, emu):
     close(gback, p2.grad.numpy())
     c = emul_counters(emu)
     assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
+
+
+def test_emulated_kernels_under_thread_sanitizer(pkg, tmp_path):
+    """The kernels once more, built with -fsanitize=thread: every fibre is a thread to the sanitizer
+    and every barrier / wave collective a release-acquire among its participants, so two threads of
+    a workgroup that meet at an LDS or global address (one of them writing) with no barrier or
+    collective in between are reported as a data race -- the kind of bug that the GPU shows only
+    now and then.  Small segments, the chunked path and the graph path must replay without a report;
+    and with the workgroup barriers hidden from the sanitizer (self-test) reports must appear, which
+    shows that the detection is alive."""
+    syn, L = pkg.synthetic, pkg._lib
+    exe = _make("emul_driver_tsan")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:exitcode=0")
+    cases = [("small", 2, 2, 96, 0.3, True, 0), ("chunked", 1, 1, 416, 0.01, False, 0),
+             ("graph", 1, 1, 416, 0.01, False, L.YP_FLAG_DENSE_NMS)]
+    for name, n_sets, B, inp_dim, conf, clustered, flags in cases:
+        sets = make_sets(pkg, n_sets, B, inp_dim, 300, clustered)
+        expected = [oracle.n_detect(heads, inp_dim, syn.YOLOV3_ANCHORS, 5, conf, 0.4)[0] for heads in sets]
+        cap = max(len(w) for w in expected) + 2 & ~1
+        path = str(tmp_path / ("%s.bin" % name))
+        write_case(path, pkg, sets, inp_dim, conf, 5, flags, cap, None, expected)
+        out = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok"), (name, out.stdout[-800:])
+        assert "ThreadSanitizer" not in out.stderr, (name, out.stderr[-4000:])
+    out = subprocess.run([exe, str(tmp_path / "small.bin")], capture_output=True, text=True, timeout=900,
+                         env=dict(env, YP_EMUL_TSAN_SELFTEST="1"))
+    assert out.stderr.count("WARNING: ThreadSanitizer: data race") >= 5, out.stderr[-2000:]
