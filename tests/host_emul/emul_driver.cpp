@@ -20,6 +20,50 @@ extern "C" void emul_stats(long *out, int reset);
 
 static bool read_exact(FILE *f, void *p, size_t n) { return n == 0 || std::fread(p, 1, n, f) == n; }
 
+// A recorded yp_match_detections call (magic 0x32455059):
+//   int32 magic, n_det, n_gt, classes, det_cap, gt_cap, 0, 0;  float thr, 0, 0, 0
+//   float rows[n_det * 8]; int32 gt_index[n_gt * 4]; float gt_boxes[n_gt * 4]; float gt_class[n_gt]
+//   int32 det_match[n_det]; float det_iou[n_det]; int32 counts[5 * classes]
+static int replay_match(FILE *f, const int32_t *h, float thr)
+{
+    const int D = h[1], G = h[2], C = h[3], det_cap = h[4], gt_cap = h[5];
+    float *rows = (float *)std::aligned_alloc(16, (size_t)det_cap * 32);
+    int32_t *gi = (int32_t *)std::malloc((size_t)gt_cap * 16);
+    float *gb = (float *)std::aligned_alloc(16, (size_t)gt_cap * 16);
+    float *gc = (float *)std::malloc((size_t)gt_cap * 4);
+    for (int i = 0; i < det_cap * 8; ++i) rows[i] = 7.0f;       // rows beyond the count look like detections
+    std::memset(gi, 0, (size_t)gt_cap * 16);
+    for (int i = 0; i < gt_cap * 4; ++i) gb[i] = 50.0f;
+    for (int i = 0; i < gt_cap; ++i) gc[i] = 1.0f;
+    if (!read_exact(f, rows, (size_t)D * 32) || !read_exact(f, gi, (size_t)G * 16) || !read_exact(f, gb, (size_t)G * 16) ||
+        !read_exact(f, gc, (size_t)G * 4))
+        return 2;
+    std::vector<int32_t> want_m(D), want_c((size_t)5 * C);
+    std::vector<float> want_iou(D);
+    if (!read_exact(f, want_m.data(), (size_t)D * 4) || !read_exact(f, want_iou.data(), (size_t)D * 4) ||
+        !read_exact(f, want_c.data(), want_c.size() * 4))
+        return 2;
+    int32_t nd = D, ng = G;
+    int32_t *match = (int32_t *)std::malloc((size_t)det_cap * 4);
+    float *iou = (float *)std::malloc((size_t)det_cap * 4);
+    int32_t *counts = (int32_t *)std::malloc((size_t)5 * C * 4);
+    const size_t need = yp_match_detections_workspace_bytes(gt_cap);
+    void *ws = std::aligned_alloc(256, need);
+    std::memset(ws, 0xA5, need);
+    std::memset(match, 0xA5, (size_t)det_cap * 4);
+    const int rc = yp_match_detections(rows, &nd, det_cap, gb, gc, gi, &ng, gt_cap, C, thr, match, iou, counts, ws, need,
+                                       nullptr);
+    if (rc != 0) { std::printf("yp_match_detections returned %d\n", rc); return 1; }
+    int bad = 0;
+    if (std::memcmp(match, want_m.data(), (size_t)D * 4) != 0) { std::printf("det_match differs\n"); ++bad; }
+    if (std::memcmp(iou, want_iou.data(), (size_t)D * 4) != 0) { std::printf("det_iou differs\n"); ++bad; }
+    if (std::memcmp(counts, want_c.data(), want_c.size() * 4) != 0) { std::printf("class counts differ\n"); ++bad; }
+    for (int i = D; i < det_cap; ++i)
+        if (match[i] != (int32_t)0xA5A5A5A5) { std::printf("det_match written beyond the count\n"); ++bad; break; }
+    std::printf("%s: matching, %d detections, %d ground-truth boxes\n", bad ? "MISMATCH" : "ok", D, G);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc != 2) return 2;
@@ -27,7 +71,9 @@ int main(int argc, char **argv)
     if (!f) return 2;
     int32_t h[8];
     float t[4];
-    if (!read_exact(f, h, sizeof h) || !read_exact(f, t, sizeof t) || h[0] != 0x31455059) return 2;
+    if (!read_exact(f, h, sizeof h) || !read_exact(f, t, sizeof t)) return 2;
+    if (h[0] == 0x32455059) return replay_match(f, h, t[0]);
+    if (h[0] != 0x31455059) return 2;
     const int n_sets = h[1], B = h[2], C = h[3], n_heads = h[4], flags = h[5], cap = h[6];
     std::vector<YpHead> heads((size_t)n_sets * n_heads);
     std::vector<size_t> elems(n_heads);

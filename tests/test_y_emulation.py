@@ -346,6 +346,38 @@ def test_emulated_decode_and_loss_kernels(pkg, emu):
     assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
 
 
+def write_match_case(path, rows, gi, gb, gc, C, thr, det_cap, gt_cap):
+    m, iou, counts = npo.match_detections(rows, gi, gb, gc, C, thr)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<8i4f", 0x32455059, len(rows), len(gb), C, det_cap, gt_cap, 0, 0, thr, 0, 0, 0))
+        for a, t in ((rows, np.float32), (gi, np.int32), (gb, np.float32), (gc, np.float32), (m, np.int32),
+                     (iou, np.float32), (counts, np.int32)):
+            f.write(np.ascontiguousarray(a, t).tobytes())
+
+
+def test_emulated_matching_kernels_under_sanitizers(pkg, tmp_path):
+    """yp_match_detections replayed under AddressSanitizer + UBSan and under ThreadSanitizer: several
+    workgroups of detections, capacities beyond the counts, and a class count on the kernels'
+    global-atomics branch."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    make_golden = importlib.import_module("make_golden")
+    exes = [(_make("emul_driver_asan"), {"ASAN_OPTIONS": "detect_leaks=0:detect_stack_use_after_return=0"},
+             ("Sanitizer:", "runtime error")),
+            (_make("emul_driver_tsan"), {"TSAN_OPTIONS": "halt_on_error=0:report_signal_unsafe=0:exitcode=0"},
+             ("ThreadSanitizer",))]
+    for seed, n_images, C, thr in ((1, 40, 5, 0.5), (4, 60, 500, 0.5)):
+        rows, gi, gb, gc = make_golden.match_random_case(seed=seed, n_images=n_images, num_classes=min(C, 7))
+        path = str(tmp_path / "match.bin")
+        write_match_case(path, rows, gi, gb, gc, C, thr, len(rows) + 300, len(gb) + 5)
+        for exe, extra, forbidden in exes:
+            out = subprocess.run([exe, path], capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
+            assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok"), (out.stdout[-800:],
+                                                                                                   out.stderr[-2000:])
+            assert not any(w in out.stderr for w in forbidden), out.stderr[-4000:]
+
+
 def test_emulated_kernels_under_thread_sanitizer(pkg, tmp_path):
     """The kernels once more, built with -fsanitize=thread: every fibre is a thread to the sanitizer
     and every barrier / wave collective a release-acquire among its participants, so two threads of
