@@ -29,6 +29,13 @@ def _make(target):
     return os.path.join(BUILD, target)
 
 
+def test_emulation_known_answers():
+    """The emulation itself: what ballots, shuffles, readlane / readfirstlane and mbcnt return in
+    uniform and in divergent control flow, what barriers order, what the atomics add up to."""
+    out = subprocess.run([_make("emul_selftest")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok "), out.stdout[-2000:]
+
+
 @pytest.fixture(scope="module")
 def emu(pkg):
     """The emulated library with the argument types of the real one."""
