@@ -8,7 +8,9 @@ arrays.  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` l
 PARITY UNPINNED: the reference ships no tests or golden vectors for this path and cannot
 be imported here (it needs TensorFlow).  The oracle is pinned by hand-derivable known
 answers, by the independent numpy restatement in ``oracle/np_oracle.py`` and by the
-reference's own encode formula (create_dataset.py:101-110) used as a round trip.
+reference's own encode formula (create_dataset.py:101-110) used as a round trip; the
+restatement of tf.image.non_max_suppression (the third-party routine behind detect_net.py:136)
+also reproduces the cases of TensorFlow's own unit test of the op (tests/tf_nms_vectors.py).
 """
 import ctypes
 import os

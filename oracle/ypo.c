@@ -32,7 +32,10 @@
  * cannot be imported here (TensorFlow absent).  This oracle is pinned only by
  * hand-derivable known answers (tests/test_oracle.py), by an independent numpy
  * restatement (oracle/np_oracle.py) and by the reference's own encode formula
- * (create_dataset.py:101-110) used as a round trip.
+ * (create_dataset.py:101-110) used as a round trip.  The one routine of the path that lives
+ * in a third-party library -- tf.image.non_max_suppression, called at detect_net.py:136;
+ * TensorFlow is neither vendored nor installed, README.md:11 implies version 2.0.0 -- is pinned
+ * to the cases of TensorFlow's own unit test of the op (tests/tf_nms_vectors.py).
  *
  * exp flavours: flavour 0 uses libm expf.  Flavour 1 uses ypo_exp_spec, a fully
  * specified sequence of IEEE-754 binary32 operations (floor, fma, mul, add) that any

@@ -400,6 +400,26 @@ def test_ref_nms_ties_and_threshold(pkg, dev, monkeypatch):
                 assert np.array_equal(np.asarray(alt[k][b]), np.asarray(want[k][b]))
 
 
+def test_ref_nms_reproduces_tensorflows_published_cases(pkg, dev, monkeypatch):
+    """The cases of TensorFlow's own unit test of tf.image.non_max_suppression (the routine the
+    reference calls at detect_net.py:136; tests/tf_nms_vectors.py) through DetectNet.filter_boxes."""
+    import tf_nms_vectors as tfv
+    P, DN = pkg.params, pkg.DetectNet
+    monkeypatch.setattr(P, "im_height", 1)
+    monkeypatch.setattr(P, "im_width", 1)
+    monkeypatch.setattr(P, "object_conf", -100.0)
+    for case in tfv.CASES:
+        boxes, scores, max_out, thr, want = tfv.arrays(case)
+        if len(scores) == 0:
+            continue
+        monkeypatch.setattr(P, "nms_conf", thr)
+        monkeypatch.setattr(P, "max_boxes", max_out)
+        tp = tuple(torch.from_numpy(a).to(dev) for a in tfv.as_decoded_tuple(boxes, scores))
+        got_boxes, got_scores, got_classes, got_index = DN.filter_boxes(tp)
+        assert np.array_equal(np.asarray(got_index[0]), want), case[0]
+        assert np.array_equal(np.asarray(got_scores[0]), scores[want]), case[0]
+
+
 def test_ref_ragged_counts_pack_as_object_array(pkg, dev, monkeypatch):
     P, DN = pkg.params, pkg.DetectNet
     pred = pkg.synthetic.make_reference_head(3, seed=5)

@@ -174,3 +174,13 @@ def test_nms_properties(seed):
     assert np.array_equal(perm[sel_p], sel)
     capped = oracle.tf_nms(boxes, scores, 7, thr)
     assert np.array_equal(capped, sel[:7])
+
+
+def test_tf_nms_restatements_reproduce_tensorflows_published_cases():
+    """Both restatements of tf.image.non_max_suppression (C and numpy) against the cases of
+    TensorFlow's own unit test of the op (tests/tf_nms_vectors.py)."""
+    import tf_nms_vectors as tfv
+    for case in tfv.CASES:
+        boxes, scores, max_out, thr, want = tfv.arrays(case)
+        assert np.array_equal(oracle.tf_nms(boxes, scores, max_out, thr), want), case[0]
+        assert np.array_equal(np.asarray(npo.tf_nms(boxes, scores, max_out, thr), np.int32), want), case[0]

@@ -215,6 +215,35 @@ def test_emulated_reference_mode(pkg, emu):
     assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
 
 
+def test_emulated_reference_nms_reproduces_tensorflows_published_cases(pkg, emu):
+    """The cases of TensorFlow's own unit test of tf.image.non_max_suppression (the routine the
+    reference calls, detect_net.py:136) through yp_filter_boxes_reference's kernels."""
+    import tf_nms_vectors as tfv
+    L = pkg._lib
+    for case in tfv.CASES:
+        boxes, scores, max_out, thr, want = tfv.arrays(case)
+        n = len(scores)
+        if n == 0:
+            continue                      # (the entry point refuses an image without rows)
+        center, wh, obj, cls = tfv.as_decoded_tuple(boxes, scores)
+        p = L.YpParams()
+        p.mode, p.batch, p.num_classes, p.max_out = L.YP_MODE_REFERENCE, 1, 5, max_out
+        p.conf_thr, p.nms_thr, p.im_h, p.im_w = -100.0, thr, 1.0, 1.0
+        need = emu.yp_rows_workspace_bytes(1, n, 1)
+        ws = aligned(need, fill=0xA5)
+        ob = aligned(max_out * 16, 16).view(np.float32).reshape(1, max_out, 4)
+        osc = np.zeros((1, max_out), np.float32)
+        ocl, oix = np.zeros((1, max_out), np.int32), np.full((1, max_out), -1, np.int32)
+        cnt, surv = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        rc = emu.yp_filter_boxes_reference(center.ctypes.data, wh.ctypes.data, obj.ctypes.data, cls.ctypes.data, n,
+                                           ctypes.byref(p), ob.ctypes.data, osc.ctypes.data, ocl.ctypes.data,
+                                           oix.ctypes.data, cnt.ctypes.data, surv.ctypes.data, ws.ctypes.data, need, None)
+        assert rc == 0, case[0]
+        assert surv[0] == n and cnt[0] == len(want), case[0]
+        assert np.array_equal(oix[0, :cnt[0]], want), case[0]
+        assert np.array_equal(osc[0, :cnt[0]], scores[want]), case[0]
+
+
 def write_case(path, pkg, sets, inp_dim, conf, C, flags, cap, frame, expected):
     n_sets, B = len(sets), sets[0][0].shape[0]
     descs = head_descs(pkg, sets[0], inp_dim, C)
