@@ -157,6 +157,31 @@ def test_params_mirror_reference_names(pkg):
     assert pkg.DetectNet.get_new_dim(416, 3, 1, 1) == 416
 
 
+def test_params_equal_the_references_own_constants(pkg):
+    """Every constant this package shares with the reference's params.py has the reference's value
+    and type of value: compared with tests/golden/reference_params.json, which
+    tests/golden/make_params_fixture.py wrote by loading the reference's module itself."""
+    import json
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    ref = json.load(open(os.path.join(here, "golden", "reference_params.json")))
+    P = pkg.params
+    shared = [k for k in ref if hasattr(P, k)]
+    # everything the post-processing path, the grid codec and the losses read
+    for needed in ("object_conf", "nms_conf", "max_boxes", "num_anchors", "num_classes", "pred_vec_len",
+                   "true_vec_len", "grid_height", "grid_width", "im_height", "im_width", "YOLO_ANCHORS",
+                   "coord_loss_weight", "obj_loss_weight", "noobj_loss_weight", "scaled_height", "scaled_width",
+                   "grid_stride"):
+        assert needed in shared, needed
+    for k in shared:
+        got = getattr(P, k)
+        if k == "YOLO_ANCHORS":
+            assert isinstance(got, np.ndarray) and got.dtype == np.float64        # a float64 literal, as there
+            assert got.tolist() == ref[k]
+        else:
+            assert got == ref[k] and type(got) is type(ref[k]), k
+
+
 def test_abi_validation_layer_under_host_sanitizers():
     """The argument validation and workspace layout code of the C ABI, compiled for the host with
     AddressSanitizer + UndefinedBehaviorSanitizer (tests/abi_sanitized.cpp linked against the
