@@ -1,4 +1,5 @@
-# A/B of compile-time variants of the large-segment NMS kernels on the GPU box.  Build the
+# A/B of compile-time variants on the GPU box: the large-segment NMS kernels (row tile, waves per
+# SIMD) and the XCD-aware tile order of the front kernel (-DYP_FRONT_XCD).  Build the
 # variants HERE first (on the CPU, before the gpurun call):
 #     bash tools/ab_variants.sh build
 # then on the GPU box (one call):
@@ -7,7 +8,7 @@
 # timed; the script stops at the first failing step, so a variant that faults never gets a second
 # launch.  Results: gpurun_out/ab_variants.txt (the HEAD of every log is kept as well).
 set -e
-VARIANTS="base: t64w4:-DYP_GRAPH_TILE=64_-DYP_GRAPH_WPE=4 t128w4:-DYP_GRAPH_TILE=128_-DYP_GRAPH_WPE=4"
+VARIANTS="base: xcd:-DYP_FRONT_XCD t64w4:-DYP_GRAPH_TILE=64_-DYP_GRAPH_WPE=4 t128w4:-DYP_GRAPH_TILE=128_-DYP_GRAPH_WPE=4"
 CSRC=2d_object_detection_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function -Iinclude -I$CSRC"
 if [ "$1" = "build" ]; then
@@ -32,5 +33,8 @@ for v in $VARIANTS; do
   CONF=0.001 timeout -k 10 120 python3 tools/nms_breakdown.py >> $OUT 2>gpurun_out/ab_$name.err || { head -n 40 gpurun_out/ab_$name.err; exit 1; }
   DENSE=1 CONF=0.5 timeout -k 10 120 python3 tools/nms_breakdown.py >> $OUT 2>>gpurun_out/ab_$name.err || { head -n 40 gpurun_out/ab_$name.err; exit 1; }
   DENSE=1 CONF=0.5 CLUSTERED=1 timeout -k 10 120 python3 tools/nms_breakdown.py >> $OUT 2>>gpurun_out/ab_$name.err || { head -n 40 gpurun_out/ab_$name.err; exit 1; }
+  # the headline configuration: throughput and the front kernel's share of the HBM roofline
+  timeout -k 10 300 python3 bench.py --no-cpu-baseline --repeats 10 > gpurun_out/ab_$name.bench.json 2>>gpurun_out/ab_$name.err || { head -n 40 gpurun_out/ab_$name.err; exit 1; }
+  python3 -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d['roofline']; print('  cfg2: %.0f images/s, front %.2f us per launch, frac %.3f alone %.3f' % (d['value'], 1e3*r['kernel_ms'], r['frac'], r['frac_alone']))" gpurun_out/ab_$name.bench.json | tee -a $OUT
 done
 cat $OUT
