@@ -170,7 +170,7 @@ class YoloV3Post:
     """Fused raw-heads -> detections engine for a fixed configuration.
 
     Buffers (workspace, output rows, count, statistics) are allocated once; ``run`` only
-    enqueues three kernels on the current stream and returns device tensors, so it can sit
+    enqueues three kernels (five with ``dense_nms``) on the current stream and returns device tensors, so it can sit
     in a serving loop without host synchronisation.  ``batch_offset`` is added to the image
     index in column 0 (used when a batch is sharded over several GPUs).  ``frame`` = (height,
     width) of the original images maps the kept boxes back from the letterboxed network input
