@@ -143,6 +143,8 @@ def comp_nms_gt(nms_boxes, gt_boxes, iou_thr=None, num_classes=None):
     if isinstance(nms_boxes, (tuple, list)) and len(nms_boxes) >= 5:
         rows, count = detection_rows(nms_boxes)
     elif isinstance(nms_boxes, (tuple, list)):
+        if len(nms_boxes) != 2:
+            raise TypeError("nms_boxes: the outputs of DetectNet.detect_device, (rows, count), or a rows tensor")
         rows, count = nms_boxes
     else:
         rows, count = nms_boxes, None
@@ -152,7 +154,7 @@ def comp_nms_gt(nms_boxes, gt_boxes, iou_thr=None, num_classes=None):
     dev = rows.device
     if count is None:
         count = torch.tensor([rows.shape[0]], dtype=torch.int32, device=dev)
-    count = _lib.require_device(count, "count").reshape(-1)[:1].to(torch.int32)
+    count = _lib.require_device(count, "count").reshape(-1)[:1].to(device=dev, dtype=torch.int32)
     if isinstance(gt_boxes, (tuple, list)):
         g_index, g_boxes, g_class, g_count = gt_boxes
     else:
