@@ -64,6 +64,61 @@ static int replay_match(FILE *f, const int32_t *h, float thr)
     return bad ? 1 : 0;
 }
 
+// A recorded yp_detect_reference call (magic 0x33455059):
+//   int32 magic, batch, grid_h, grid_w, anchors, classes, max_out, 0;  float conf, nms, im_h, im_w
+//   float anchors[2 * anchors]; float pred[batch * grid_h * grid_w * anchors * (5 + classes)]
+//   int32 counts[batch], surv[batch]; then per image: float boxes[n*4], float scores[n], int32 classes[n], int32 index[n]
+static int replay_reference(FILE *f, const int32_t *h, const float *t)
+{
+    const int B = h[1], H = h[2], W = h[3], A = h[4], C = h[5], mb = h[6];
+    YpHead head;
+    std::memset(&head, 0, sizeof head);
+    head.grid_h = H; head.grid_w = W; head.num_anchors = A;
+    if (!read_exact(f, head.anchors, (size_t)2 * A * 4)) return 2;
+    const size_t n_pred = (size_t)B * H * W * A * (5 + C);
+    float *pred = (float *)std::aligned_alloc(16, (n_pred * 4 + 15) / 16 * 16);
+    if (!read_exact(f, pred, n_pred * 4)) return 2;
+    head.data = pred;
+    YpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.mode = YP_MODE_REFERENCE; p.batch = B; p.num_classes = C; p.max_out = mb;
+    p.conf_thr = t[0]; p.nms_thr = t[1]; p.im_h = t[2]; p.im_w = t[3];
+    const size_t need = yp_detect_reference_workspace_bytes(B, H, W, A);
+    void *ws = std::aligned_alloc(256, need);
+    std::memset(ws, 0xA5, need);
+    float *boxes = (float *)std::aligned_alloc(16, (size_t)B * mb * 16);
+    float *scores = (float *)std::malloc((size_t)B * mb * 4);
+    int32_t *classes = (int32_t *)std::malloc((size_t)B * mb * 4), *index = (int32_t *)std::malloc((size_t)B * mb * 4);
+    int32_t *counts = (int32_t *)std::malloc((size_t)B * 4), *surv = (int32_t *)std::malloc((size_t)B * 4);
+    const int rc = yp_detect_reference(&head, &p, boxes, scores, classes, index, counts, surv, ws, need, nullptr);
+    if (rc != 0) { std::printf("yp_detect_reference returned %d\n", rc); return 1; }
+    std::vector<int32_t> want_counts(B), want_surv(B);
+    if (!read_exact(f, want_counts.data(), (size_t)B * 4) || !read_exact(f, want_surv.data(), (size_t)B * 4)) return 2;
+    int bad = 0;
+    if (std::memcmp(counts, want_counts.data(), (size_t)B * 4) != 0) { std::printf("counts differ\n"); ++bad; }
+    if (std::memcmp(surv, want_surv.data(), (size_t)B * 4) != 0) { std::printf("survivor counts differ\n"); ++bad; }
+    for (int b = 0; b < B && !bad; ++b) {
+        const int n = want_counts[b];
+        std::vector<float> wb((size_t)n * 4), wsc(n);
+        std::vector<int32_t> wc(n), wi(n);
+        if (!read_exact(f, wb.data(), wb.size() * 4) || !read_exact(f, wsc.data(), (size_t)n * 4) ||
+            !read_exact(f, wc.data(), (size_t)n * 4) || !read_exact(f, wi.data(), (size_t)n * 4))
+            return 2;
+        if (std::memcmp(boxes + (size_t)b * mb * 4, wb.data(), wb.size() * 4) != 0 ||
+            std::memcmp(scores + (size_t)b * mb, wsc.data(), (size_t)n * 4) != 0 ||
+            std::memcmp(classes + (size_t)b * mb, wc.data(), (size_t)n * 4) != 0 ||
+            std::memcmp(index + (size_t)b * mb, wi.data(), (size_t)n * 4) != 0) {
+            std::printf("image %d differs\n", b);
+            ++bad;
+        }
+    }
+    long st[5];
+    emul_stats(st, 0);
+    std::printf("%s: reference mode, %d images, %ld divergent groups, %ld shuffles from inactive lanes\n",
+                bad ? "MISMATCH" : "ok", B, st[1], st[2]);
+    return bad || st[1] || st[2] ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc != 2) return 2;
@@ -73,6 +128,7 @@ int main(int argc, char **argv)
     float t[4];
     if (!read_exact(f, h, sizeof h) || !read_exact(f, t, sizeof t)) return 2;
     if (h[0] == 0x32455059) return replay_match(f, h, t[0]);
+    if (h[0] == 0x33455059) return replay_reference(f, h, t);
     if (h[0] != 0x31455059) return 2;
     const int n_sets = h[1], B = h[2], C = h[3], n_heads = h[4], flags = h[5], cap = h[6];
     std::vector<YpHead> heads((size_t)n_sets * n_heads);

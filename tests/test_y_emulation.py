@@ -414,6 +414,39 @@ def test_emulated_matching_kernels_under_sanitizers(pkg, tmp_path):
             assert not any(w in out.stderr for w in forbidden), out.stderr[-4000:]
 
 
+def test_emulated_reference_mode_under_sanitizers(pkg, tmp_path):
+    """yp_detect_reference -- the reference's own configuration (13 x 13 grid, 5 anchors, conf 0.6,
+    NMS 0.5, 20 boxes) on relu'd heads with many survivors -- replayed under AddressSanitizer + UBSan
+    and under ThreadSanitizer against the oracle's per-image outputs."""
+    P = pkg.params
+    B, H, W, A, C, mb = 6, 13, 13, 5, 5, 20
+    pred = np.ascontiguousarray(pkg.synthetic.make_reference_head(B, seed=91, relu=True, obj_mean=0.5).numpy())
+    anc = np.asarray(P.YOLO_ANCHORS, np.float32).reshape(-1, 2)
+    ob, os_, oc, oi, osurv = oracle.r_detect(pred, H, W, A, C, anc, P.object_conf, P.nms_conf, mb, P.im_height,
+                                             P.im_width)
+    assert sum(len(s) for s in os_) > B            # the case keeps boxes in every image on average
+    path = str(tmp_path / "reference.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<8i4f", 0x33455059, B, H, W, A, C, mb, 0, P.object_conf, P.nms_conf, P.im_height,
+                            P.im_width))
+        f.write(np.ascontiguousarray(anc, np.float32).tobytes())
+        f.write(pred.astype(np.float32).tobytes())
+        f.write(np.asarray([len(s) for s in os_], np.int32).tobytes())
+        f.write(np.asarray(osurv, np.int32).tobytes())
+        for b in range(B):
+            for a, t in ((ob[b], np.float32), (os_[b], np.float32), (oc[b], np.int32), (oi[b], np.int32)):
+                f.write(np.ascontiguousarray(a, t).tobytes())
+    runs = [(_make("emul_driver_asan"), {"ASAN_OPTIONS": "detect_leaks=0:detect_stack_use_after_return=0"},
+             ("Sanitizer:", "runtime error")),
+            (_make("emul_driver_tsan"), {"TSAN_OPTIONS": "halt_on_error=0:report_signal_unsafe=0:exitcode=0"},
+             ("ThreadSanitizer",))]
+    for exe, extra, forbidden in runs:
+        out = subprocess.run([exe, path], capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
+        assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok"), (out.stdout[-800:],
+                                                                                               out.stderr[-2000:])
+        assert not any(w in out.stderr for w in forbidden), out.stderr[-4000:]
+
+
 def test_emulated_kernels_under_thread_sanitizer(pkg, tmp_path):
     """The kernels once more, built with -fsanitize=thread: every fibre is a thread to the sanitizer
     and every barrier / wave collective a release-acquire among its participants, so two threads of
