@@ -215,6 +215,50 @@ def test_emulated_reference_mode(pkg, emu):
     assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
 
 
+def test_emulated_reference_mode_random_geometry(pkg, emu):
+    """yp_detect_reference on random grids (also non-square ones, where the reference's own index
+    construction matters), 1..8 anchors, up to 64 classes, thresholds at their extremes and output
+    caps from 1 to 5000, against the oracle."""
+    L = pkg._lib
+    rs = np.random.RandomState(2024)
+    for it in range(30):
+        H, W = int(rs.randint(1, 30)), int(rs.randint(1, 30))
+        A, C = int(rs.randint(1, 9)), int(rs.choice([1, 2, 5, 5, 20, 64]))
+        B = int(rs.randint(1, 5))
+        mb = int(rs.choice([1, 3, 20, 20, 200, 5000]))
+        conf = float(rs.choice([0.0, 0.05, 0.3, 0.6, 0.9]))
+        nms = float(rs.choice([0.0, 0.3, 0.5, 0.5, 0.9, 1.0]))
+        im_h, im_w = float(rs.choice([1, 416, 1280])), float(rs.choice([1, 416, 1920]))
+        pred = rs.normal(rs.choice([-1.0, 0.0, 1.0]), rs.choice([0.5, 1.5, 3.0]), (B, H * W * A * (5 + C)))
+        pred = np.ascontiguousarray((np.maximum(pred, 0) if rs.randint(2) else pred).astype(np.float32))
+        anc = np.ascontiguousarray(rs.uniform(0.3, 10, (A, 2)).astype(np.float32))
+        head = L.make_head(None, H, W, [tuple(a) for a in anc])
+        head.data = pred.ctypes.data
+        p = L.YpParams()
+        p.mode, p.batch, p.num_classes, p.max_out = L.YP_MODE_REFERENCE, B, C, mb
+        p.conf_thr, p.nms_thr, p.im_h, p.im_w = conf, nms, im_h, im_w
+        need = emu.yp_detect_reference_workspace_bytes(B, H, W, A)
+        ws = aligned(need, fill=0xA5)
+        boxes = aligned(B * mb * 16, 16).view(np.float32).reshape(B, mb, 4)
+        scores = np.zeros((B, mb), np.float32)
+        classes, index = np.zeros((B, mb), np.int32), np.zeros((B, mb), np.int32)
+        counts, surv = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        rc = emu.yp_detect_reference(ctypes.byref(head), ctypes.byref(p), boxes.ctypes.data, scores.ctypes.data,
+                                     classes.ctypes.data, index.ctypes.data, counts.ctypes.data, surv.ctypes.data,
+                                     ws.ctypes.data, need, None)
+        tag = (it, H, W, A, C, B, mb, conf, nms)
+        assert rc == 0, tag
+        ob, os_, oc, oi, osurv = oracle.r_detect(pred, H, W, A, C, anc, conf, nms, mb, im_h, im_w)
+        assert np.array_equal(surv, osurv), tag
+        for b in range(B):
+            n = counts[b]
+            assert n == len(os_[b]), tag
+            assert np.array_equal(boxes[b, :n], ob[b]) and np.array_equal(scores[b, :n], os_[b]), tag
+            assert np.array_equal(classes[b, :n], oc[b]) and np.array_equal(index[b, :n], oi[b]), tag
+    c = emul_counters(emu)
+    assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
+
+
 def test_emulated_reference_nms_reproduces_tensorflows_published_cases(pkg, emu):
     """The cases of TensorFlow's own unit test of tf.image.non_max_suppression (the routine the
     reference calls, detect_net.py:136) through yp_filter_boxes_reference's kernels."""
