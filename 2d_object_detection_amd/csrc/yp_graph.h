@@ -45,6 +45,13 @@ constexpr int kGraphEdges = 8;            // recorded suppressors per column (th
 #ifndef YP_GRAPH_WAVEMODE
 #define YP_GRAPH_WAVEMODE 0
 #endif
+// Columns of a k_graph_pairs batch: 64 (one per lane), or 32 / 16 with every column held by
+// 2 / 4 lanes that test it against different rows at the same time.  A narrower batch covers a
+// smaller patch of the plane, so fewer rows reach it; the number of batches grows instead.
+#ifndef YP_GRAPH_COLS
+#define YP_GRAPH_COLS 64
+#endif
+static_assert(YP_GRAPH_COLS == 64 || YP_GRAPH_COLS == 32 || YP_GRAPH_COLS == 16, "columns per batch");
 constexpr int kGraphRowTile = YP_GRAPH_TILE;   // candidate rows a wave fetches per pass
 constexpr int kGraphThreads = 256;        // k_graph_pairs workgroup
 constexpr int kGraphWaves = kGraphThreads / 64;
@@ -147,6 +154,8 @@ __device__ __forceinline__ int wave_max_i(int v)
 }
 
 constexpr int kGraphBuf = kGraphRowTile + 64;   // useful rows a wave collects before testing
+constexpr int kGraphCols = YP_GRAPH_COLS;
+static_assert(kGraphBuf % (4 * (64 / kGraphCols)) == 0, "padding of a flush stays inside the buffer");
 
 // Per-wave LDS of a walk.
 struct GraphWaveShared {
@@ -187,7 +196,9 @@ __device__ __forceinline__ void graph_record(int *gcnt, int *gedge, int target, 
 // Candidate rows are looked at by one lane each when they are fetched: a row that cannot touch
 // the batch's bounding box, whose class is out of order for the pair rule, or that is already
 // suppressed (REBUILD) is dropped there; the others are packed into LDS, and whenever enough
-// have gathered they are tested four at a time (uniform) against the 64 columns.
+// have gathered they are tested four at a time (uniform) against the 64 columns.  With COLS < 64
+// columns per batch (k_graph_pairs only) lane l holds column l % COLS and takes the rows
+// l / COLS, 64 / COLS + l / COLS, ... of every group of 4 * 64 / COLS rows.
 template <int MODE, bool REBUILD>
 __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, const float4 *xraw,
                                           const int *xidx, const unsigned char *status, int *gcnt,
@@ -197,6 +208,8 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
                                           unsigned int &ties, bool &kept_hit)
 {
     const int lane = threadIdx.x & 63;
+    constexpr int COLS = REBUILD ? 64 : kGraphCols, REP = 64 / COLS;
+    const int rslot = REP == 1 ? 0 : lane / COLS;     // which of the REP rows of a step this lane takes
     const YpBox bj = {cj.x, cj.y, cj.z, cj.w};
     const YpPrep pj = yp_prep<MODE>(bj);
     // classes and extent of the batch (uniform)
@@ -205,7 +218,7 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
     const float inf = __builtin_inff();
     const float bxlo = wave_min_f(live ? pj.lo0 : inf), bxhi = wave_max_f(live ? pj.hi0 : -inf);
     const float bylo = wave_min_f(live ? pj.lo1 : inf), byhi = wave_max_f(live ? pj.hi1 : -inf);
-    const int n_live = __popcll(__ballot(live));
+    const int n_live = __popcll(__ballot(live) & (COLS == 64 ? ~0ull : (1ull << (COLS & 63)) - 1ull));
     int cnt = 0, first = 0x7fffffff;
     kept_hit = false;
     if (cB < 0) return 0;
@@ -216,10 +229,11 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
     int n_buf = 0;      // useful rows waiting in LDS (uniform)
     // test the waiting rows against the columns, four (uniform) rows at a time
     auto flush = [&]() {
-        // pad to a multiple of four with rows that cannot record anything
-        if (lane < 4) {
+        // pad to a multiple of four (times REP) with rows that cannot record anything
+        constexpr int G = 4 * REP;
+        if (lane < G) {
             const int q = n_buf + lane;
-            if (q < ((n_buf + 3) & ~3)) {
+            if (q < ((n_buf + G - 1) & ~(G - 1))) {
                 ws.row[q] = make_float4(3e38f, 3e38f, 3e38f, 3e38f);
                 ws.area[q] = 1.0f;
                 ws.rank[q] = 0x7fffffff;
@@ -228,16 +242,17 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int r0 = 0; r0 < n_buf; r0 += 4) {
+        for (int r0 = 0; r0 < n_buf; r0 += G) {
             float4 ci[4];
             float ai[4];
             int rk[4], pc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                ci[u] = ws.row[r0 + u];
-                ai[u] = ws.area[r0 + u];
-                rk[u] = ws.rank[r0 + u];
-                pc[u] = ws.pc[r0 + u];
+                const int q = r0 + u * REP + rslot;
+                ci[u] = ws.row[q];
+                ai[u] = ws.area[q];
+                rk[u] = ws.rank[q];
+                pc[u] = ws.pc[q];
             }
             u64 words[4];
             suppress_words<MODE, 4>(pj, live, ci, ai, thr, words, ties);
@@ -406,7 +421,7 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
         const float4 *xraw = a.xraw + reg;
         const int *xidx = a.xidx + reg;
         unsigned int pairs = 0, ties = 0;
-        const int n_batches = (K + 63) >> 6;
+        const int n_batches = kGraphCols == 64 ? (K + 63) >> 6 : (K + kGraphCols - 1) / kGraphCols;
         const int start = (int)((blockIdx.x + (unsigned)t * 37u) % gridDim.x);
         // With batches to spare every wave takes a batch of its own (the window set-up is then
         // paid once per batch); with few of them the waves of a workgroup share one batch's tiles.
@@ -414,7 +429,7 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
         for (int grp = start; grp * per_wg < n_batches; grp += gridDim.x) {
             const int batch = wave_mode ? grp * kGraphWaves + wave : grp;
             if (batch >= n_batches) continue;
-            const int p = batch * 64 + lane;
+            const int p = batch * kGraphCols + (lane & (kGraphCols - 1));
             const bool live = p < K;
             const float4 cj = xraw[live ? p : K - 1];
             const int my_rank = live ? xidx[p] : -1;

@@ -36,10 +36,9 @@ def test_emulation_known_answers():
     assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok "), out.stdout[-2000:]
 
 
-@pytest.fixture(scope="module")
-def emu(pkg):
-    """The emulated library with the argument types of the real one."""
-    lib = ctypes.CDLL(_make("libyolopost_emul.so"))
+def load_emulated(pkg, target):
+    """An emulated build of the library with the argument types of the real one."""
+    lib = ctypes.CDLL(_make(target))
     real = pkg._lib.load()
     for name in pkg._lib.EXPORTED_SYMBOLS:
         fn, ref = getattr(lib, name), getattr(real, name)
@@ -47,6 +46,11 @@ def emu(pkg):
         if ref.argtypes is not None:
             fn.argtypes = ref.argtypes
     return lib
+
+
+@pytest.fixture(scope="module")
+def emu(pkg):
+    return load_emulated(pkg, "libyolopost_emul.so")
 
 
 def aligned(nbytes, align=256, fill=0):
@@ -133,6 +137,28 @@ def test_emulated_detect_matches_oracle(pkg, emu, name, n_sets, B, inp_dim, conf
             assert st[k, 0].max() > 768          # the case does exercise the large-segment code
         # rows beyond the count were never written
         assert (out[k, len(want):].view(np.uint8) == 0xA5).all()
+
+
+def test_emulated_narrow_batches_of_the_pair_kernel(pkg):
+    """-DYP_GRAPH_COLS=16: a batch of k_graph_pairs is 16 columns, each held by four lanes that test
+    it against four different rows at a time.  Same rows as the oracle on the graph path, fewer
+    pair tests than the 64-column build (a narrower batch is reached by fewer rows), every
+    collective still wave-uniform."""
+    syn = pkg.synthetic
+    libs = {name: load_emulated(pkg, name) for name in ("libyolopost_emul.so", "libyolopost_emul_c16.so")}
+    sets = make_sets(pkg, 2, 1, (320, 480), 500, True)
+    pairs = {}
+    for name, lib in libs.items():
+        emul_counters(lib)
+        out, cnt, st = run_detect(pkg, lib, sets, (320, 480), 0.01, dense=True)
+        c = emul_counters(lib)
+        assert c["launches"] == 5 and c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, (name, c)
+        for k, heads in enumerate(sets):
+            want, surv, _ = oracle.n_detect(heads, (320, 480), syn.YOLOV3_ANCHORS, 5, 0.01, 0.4)
+            assert cnt[k] == len(want) and np.array_equal(out[k, :len(want)], want), name
+            assert st[k, 0].max() > 768
+        pairs[name] = int(st[:, 2].astype(np.int64).sum())
+    assert pairs["libyolopost_emul_c16.so"] < 0.8 * pairs["libyolopost_emul.so"], pairs
 
 
 def test_emulated_capacity_overflow_and_single_entry(pkg, emu):

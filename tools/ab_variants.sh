@@ -1,5 +1,7 @@
-# A/B of compile-time variants on the GPU box: the large-segment NMS kernels (row tile, waves per
-# SIMD) and the XCD-aware tile order of the front kernel (-DYP_FRONT_XCD).  Build the
+# A/B of compile-time variants on the GPU box: the large-segment NMS kernels (columns per batch,
+# row tile, waves per SIMD) and the XCD-aware tile order of the front kernel (-DYP_FRONT_XCD).
+# The variants in the shipped resource class (no scratch, 3 waves per SIMD) come first; the ones
+# that change the occupancy target come last, so a fault there costs nothing before it.  Build the
 # variants HERE first (on the CPU, before the gpurun call):
 #     bash tools/ab_variants.sh build
 # then on the GPU box (one call):
@@ -8,7 +10,7 @@
 # timed; the script stops at the first failing step, so a variant that faults never gets a second
 # launch.  Results: gpurun_out/ab_variants.txt (the HEAD of every log is kept as well).
 set -e
-VARIANTS="base: xcd:-DYP_FRONT_XCD t64w4:-DYP_GRAPH_TILE=64_-DYP_GRAPH_WPE=4 t128w4:-DYP_GRAPH_TILE=128_-DYP_GRAPH_WPE=4"
+VARIANTS="base: xcd:-DYP_FRONT_XCD c32:-DYP_GRAPH_COLS=32 c16:-DYP_GRAPH_COLS=16 t64w4:-DYP_GRAPH_TILE=64_-DYP_GRAPH_WPE=4 t128w4:-DYP_GRAPH_TILE=128_-DYP_GRAPH_WPE=4 c16t64w4:-DYP_GRAPH_COLS=16_-DYP_GRAPH_TILE=64_-DYP_GRAPH_WPE=4"
 CSRC=2d_object_detection_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function -Iinclude -I$CSRC"
 if [ "$1" = "build" ]; then
