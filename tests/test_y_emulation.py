@@ -330,6 +330,16 @@ def write_case(path, pkg, sets, inp_dim, conf, C, flags, cap, frame, expected):
             f.write(np.ascontiguousarray(want[:cap], np.float32).tobytes())
 
 
+def replay_all(replays, workers=4):
+    """Runs (label, argv, env) replays of recorded calls, a few at a time (they are independent
+    single-threaded processes), and returns [(label, CompletedProcess)] in the order given."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        runs = [pool.submit(subprocess.run, argv, capture_output=True, text=True, timeout=900, env=env)
+                for _, argv, env in replays]
+        return [(label, r.result()) for (label, _, _), r in zip(replays, runs)]
+
+
 def test_emulated_kernels_under_address_and_ub_sanitizers(pkg, tmp_path):
     """The same kernels, built with -fsanitize=address,undefined, replaying recorded calls whose
     buffers are heap blocks of exactly the documented sizes: small segments, the chunked
@@ -347,23 +357,24 @@ def test_emulated_kernels_under_address_and_ub_sanitizers(pkg, tmp_path):
          (1280.0, 1920.0), 0.3),
     ]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0")
-    for name, n_sets, B, inp_dim, conf, clustered, flags, frame, cap_frac in cases:
+    replays = []
+    for k, (name, n_sets, B, inp_dim, conf, clustered, flags, frame, cap_frac) in enumerate(cases):
         sets = make_sets(pkg, n_sets, B, inp_dim, 300, clustered)
         expected = []
         for heads in sets:
             want, _, _ = oracle.n_detect(heads, inp_dim, syn.YOLOV3_ANCHORS, 5, conf, 0.4)
             expected.append(npo.n_rescale(want, inp_dim, frame) if frame is not None else want)
         cap = max(2, int(max(len(w) for w in expected) * cap_frac) + 2 & ~1)
-        path = str(tmp_path / "case.bin")
+        path = str(tmp_path / ("case%d.bin" % k))
         write_case(path, pkg, sets, inp_dim, conf, 5, flags, cap, frame, expected)
         # workgroups of a launch run in any order on the GPU: the graph path (atomics between
         # workgroups) is replayed with the workgroups last to first and in a scrambled order as well
         for order in (("", "reverse", "shuffle") if name == "graph" else ("",)):
-            out = subprocess.run([exe, path], capture_output=True, text=True, timeout=600,
-                                 env=dict(env, YP_EMUL_ORDER=order))
-            assert out.returncode == 0, (name, order, out.stdout[-1500:], out.stderr[-3000:])
-            assert out.stdout.strip().splitlines()[-1].startswith("ok"), (name, order, out.stdout[-500:])
-            assert "Sanitizer:" not in out.stderr and "runtime error" not in out.stderr, (name, order, out.stderr[-3000:])
+            replays.append((name + " " + order, [exe, path], dict(env, YP_EMUL_ORDER=order)))
+    for label, out in replay_all(replays):
+        assert out.returncode == 0, (label, out.stdout[-1500:], out.stderr[-3000:])
+        assert out.stdout.strip().splitlines()[-1].startswith("ok"), (label, out.stdout[-500:])
+        assert "Sanitizer:" not in out.stderr and "runtime error" not in out.stderr, (label, out.stderr[-3000:])
 
 
 def test_emulated_grid_codec_matches_golden(pkg, emu):
@@ -530,15 +541,17 @@ def test_emulated_kernels_under_thread_sanitizer(pkg, tmp_path):
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:exitcode=0")
     cases = [("small", 2, 2, 96, 0.3, True, 0), ("chunked", 1, 1, 416, 0.01, False, 0),
              ("graph", 1, 1, 416, 0.01, False, L.YP_FLAG_DENSE_NMS)]
+    replays = []
     for name, n_sets, B, inp_dim, conf, clustered, flags in cases:
         sets = make_sets(pkg, n_sets, B, inp_dim, 300, clustered)
         expected = [oracle.n_detect(heads, inp_dim, syn.YOLOV3_ANCHORS, 5, conf, 0.4)[0] for heads in sets]
         cap = max(len(w) for w in expected) + 2 & ~1
         path = str(tmp_path / ("%s.bin" % name))
         write_case(path, pkg, sets, inp_dim, conf, 5, flags, cap, None, expected)
-        out = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=env)
+        replays.append((name, [exe, path], env))
+    replays.append(("self-test", [exe, str(tmp_path / "small.bin")], dict(env, YP_EMUL_TSAN_SELFTEST="1")))
+    results = replay_all(replays)
+    for name, out in results[:-1]:
         assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok"), (name, out.stdout[-800:])
         assert "ThreadSanitizer" not in out.stderr, (name, out.stderr[-4000:])
-    out = subprocess.run([exe, str(tmp_path / "small.bin")], capture_output=True, text=True, timeout=900,
-                         env=dict(env, YP_EMUL_TSAN_SELFTEST="1"))
-    assert out.stderr.count("WARNING: ThreadSanitizer: data race") >= 5, out.stderr[-2000:]
+    assert results[-1][1].stderr.count("WARNING: ThreadSanitizer: data race") >= 5, results[-1][1].stderr[-2000:]
