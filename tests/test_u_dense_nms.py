@@ -75,7 +75,8 @@ def test_cfg5_full_batch_properties(pkg, dev):
     properties that do not depend on the size: both NMS paths give the same bytes; images are
     independent (the first image alone gives the same rows, and those equal the oracle's); rows
     are ordered image -> class -> objectness; counts add up; and inside a segment no two kept
-    boxes reach the threshold (what greedy NMS guarantees)."""
+    boxes exceed the threshold (what greedy NMS guarantees; the quotient is formed with the same
+    binary32 operations in the same order as the kernel's exact test, so equality is the limit)."""
     import os
     syn, util = pkg.synthetic, pkg.util
     B = int(os.environ.get("YP_TEST_CFG5_BATCH", "32"))
@@ -108,7 +109,7 @@ def test_cfg5_full_batch_properties(pkg, dev):
     assert torch.equal(first, got[:n0])
     want, _, _ = oracle.n_detect([h[:1].numpy() for h in heads], inp_dim, syn.YOLOV3_ANCHORS, 5, conf, thr)
     assert np.array_equal(first.cpu().numpy(), want)
-    # no two kept boxes of a segment reach the threshold (pixel-inclusive IoU, as the path defines it)
+    # no two kept boxes of a segment exceed the threshold (pixel-inclusive IoU, as the path defines it)
     for b, c in ((0, 0), (B - 1, 4), (B // 2, 2)):
         seg = got[(img == b) & (cls == c)][:, 1:5]
         n = seg.shape[0]
@@ -122,4 +123,4 @@ def test_cfg5_full_batch_properties(pkg, dev):
             iou = inter / (area[lo:lo + 2048, None] + area[None, :] - inter)
             iou[torch.arange(a.shape[0]), torch.arange(lo, lo + a.shape[0])] = 0.0      # a box with itself
             worst = max(worst, float(iou.max()))
-        assert worst < thr, (b, c, worst)
+        assert worst <= thr, (b, c, worst)
