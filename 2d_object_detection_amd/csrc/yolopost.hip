@@ -2573,6 +2573,9 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
         ga.seg_kept = w.seg_kept;
         ga.seg_pairs = w.seg_pairs;
         ga.seg_ties = w.seg_ties;
+#if YP_RESOLVE_WORKLIST
+        ga.work = reinterpret_cast<int *>(w.sbox);
+#endif
         // pair tests: a fixed number of workgroups that share out the batches of all graph
         // segments; resolve: one workgroup per graph segment (those beyond their number leave)
         const long long slots_all = (long long)n_seg / p->num_classes * spi;

@@ -10,7 +10,7 @@
 # timed; the script stops at the first failing step, so a variant that faults never gets a second
 # launch.  Results: gpurun_out/ab_variants.txt (the HEAD of every log is kept as well).
 set -e
-VARIANTS="base: xcd:-DYP_FRONT_XCD c32:-DYP_GRAPH_COLS=32 c16:-DYP_GRAPH_COLS=16 t64w4:-DYP_GRAPH_TILE=64,-DYP_GRAPH_WPE=4 t128w4:-DYP_GRAPH_TILE=128,-DYP_GRAPH_WPE=4 c16t64w4:-DYP_GRAPH_COLS=16,-DYP_GRAPH_TILE=64,-DYP_GRAPH_WPE=4"
+VARIANTS="base: xcd:-DYP_FRONT_XCD c32:-DYP_GRAPH_COLS=32 c16:-DYP_GRAPH_COLS=16 wl:-DYP_RESOLVE_WORKLIST=1 t64w4:-DYP_GRAPH_TILE=64,-DYP_GRAPH_WPE=4 t128w4:-DYP_GRAPH_TILE=128,-DYP_GRAPH_WPE=4 c16t64w4:-DYP_GRAPH_COLS=16,-DYP_GRAPH_TILE=64,-DYP_GRAPH_WPE=4"
 CSRC=2d_object_detection_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function -Iinclude -I$CSRC"
 if [ "$1" = "build" ]; then
