@@ -20,6 +20,7 @@ from oracle import np_oracle as npo
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMUL = os.path.join(HERE, "host_emul")
 BUILD = os.path.join(HERE, "_build")
+ROOT = os.path.dirname(HERE)
 
 
 def _make(target):
@@ -159,6 +160,29 @@ def test_emulated_narrow_batches_of_the_pair_kernel(pkg):
             assert st[k, 0].max() > 768
         pairs[name] = int(st[:, 2].astype(np.int64).sum())
     assert pairs["libyolopost_emul_c16.so"] < 0.8 * pairs["libyolopost_emul.so"], pairs
+
+
+def test_ab_script_variants_are_valid_builds():
+    """Every compile-time variant tools/ab_variants.sh builds for the GPU box parses with its
+    defines (host compiler, emulation header, syntax only), and the script itself parses."""
+    if shutil.which("g++") is None or shutil.which("bash") is None:
+        pytest.skip("g++ / bash are not installed here")
+    script = os.path.join(ROOT, "tools", "ab_variants.sh")
+    assert subprocess.run(["bash", "-n", script]).returncode == 0
+    text = open(script).read()
+    assert "tr ',' ' '" in text          # (the separator this test splits the defines at)
+    line = [l for l in text.splitlines() if l.startswith("VARIANTS=")]
+    assert len(line) == 1
+    variants = dict(v.split(":", 1) for v in line[0].split('"')[1].split())
+    assert "base" in variants and variants["base"] == "" and len(variants) >= 4
+    csrc = os.path.join(ROOT, "2d_object_detection_amd", "csrc")
+    for name, defs in variants.items():
+        defs = [d for d in defs.split(",") if d]
+        assert all(d.startswith("-DYP_") for d in defs), (name, defs)
+        out = subprocess.run(["g++", "-std=c++20", "-fsyntax-only", "-Wno-attributes", "-I" + EMUL,
+                              "-I" + os.path.join(ROOT, "include"), "-I" + csrc] + defs +
+                             [os.path.join(EMUL, "emul_yolopost.cpp")], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (name, out.stderr[-2000:])
 
 
 def test_emulated_capacity_overflow_and_single_entry(pkg, emu):
