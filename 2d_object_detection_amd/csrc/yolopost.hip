@@ -139,6 +139,8 @@ struct SegArgs {
     int *glist;              // graph segments of the launch, indexed like the tables
     int *gcnt, *gedge;       // suppressor records the graph kernels fill (cleared here)
     int *ctrl;               // launch control words (see CandBuf)
+    int *img_flag;           // [B] set by k_image_nms: 0 = that kernel finished the image, 1 = it is
+                             // left to k_segment_nms (null: k_image_nms did not run)
     // reference-mode outputs, padded to max_out rows per image
     float *out_boxes;
     float *out_scores;
@@ -1363,6 +1365,7 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
 }
 
 #include "yp_graph.h"
+#include "yp_image.h"
 
 template <int MODE>
 #ifndef YP_PAIR_UNROLL
@@ -1411,6 +1414,8 @@ void k_segment_nms(SegArgs s)
     if (tid == 0) s_pairs = 0u;
     if (tid == 1) s_ties = 0u;
     if (MODE == YP_MODE_YOLOV3 && tid == 0 && s.gseg) s.gseg[seg].K = 0;
+    // an image the per-image kernel has finished needs nothing here
+    if (MODE == YP_MODE_YOLOV3 && s.img_flag != nullptr && s.img_flag[b] == 0) return;
     STAMP(0);
 
     // ---- exclusive prefix of the image's tile counts: a kept row's position in the image's
@@ -2300,6 +2305,7 @@ struct Workspace {
     int *bin_tables;
     int *glist;
     int *ctrl;
+    int *img_flag;
 };
 
 template <class T>
@@ -2335,6 +2341,7 @@ size_t carve(void *base_v, size_t slots, size_t tiles, size_t n_seg, Workspace *
     off = carve_one(base, off, n_seg, &w->seg_pairs);
     off = carve_one(base, off, n_seg, &w->seg_ties);
     off = carve_one(base, off, 16, &w->ctrl);
+    off = carve_one(base, off, n_seg, &w->img_flag);   // (one per image; n_seg >= images)
     w->gcnt = nullptr;
     w->gedge = nullptr;
     w->gseg = nullptr;
@@ -2489,6 +2496,7 @@ SegArgs make_seg_args(const Workspace &w, const YpParams *p, int spi, int tpi, i
     s.gcnt = w.gcnt;
     s.gedge = w.gedge;
     s.ctrl = w.ctrl;
+    s.img_flag = nullptr;
     s.dbg = g_dbg;
     return s;
 }
@@ -2505,7 +2513,8 @@ struct ProfileState {
                                      // graph pairs, graph resolve)
     unsigned char *launched = nullptr;  // per call: bit k set when kernel k was launched
 };
-constexpr int kProfKernels = 5, kProfEvents = 2 * kProfKernels;
+constexpr int kProfKernels = 6, kProfEvents = 2 * kProfKernels;   // (the last one is k_image_nms)
+constexpr int kProfReported = 5;   // yp_profile_stop_ex: k_image_nms is added to the segment NMS time
 ProfileState g_prof;
 
 inline bool prof_active() { return g_prof.on && g_prof.calls < g_prof.max_calls; }
@@ -2521,7 +2530,7 @@ inline void prof_next()
     if (prof_active()) ++g_prof.calls;
 }
 
-// k: 0 front, 1 segment NMS, 2 gather, 3 graph pairs, 4 graph resolve.
+// k: 0 front, 1 segment NMS, 2 gather, 3 graph pairs, 4 graph resolve, 5 image NMS.
 #define YP_LAUNCH(k, kernel, grid, block, lds, st, ...)                                          \
     do {                                                                                         \
         if (prof_active())                                                                       \
@@ -2549,6 +2558,13 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
     // launches cost a few microseconds per call even when no segment is large.
     const bool dense = (p->flags & YP_FLAG_DENSE_NMS) != 0 && w.gseg != nullptr && spi > kGraphMin;
     if (!dense) s.gseg = nullptr;
+    // Images of moderate size are finished by one workgroup each (k_image_nms); that kernel flags
+    // the images it cannot take, and k_segment_nms, launched behind it, only works on those.
+    const bool per_image = p->num_classes <= kImgMaxClasses && tpi <= kImgMaxTiles &&
+                           yp_make_thr(p->nms_thr).fast;
+    if (per_image) s.img_flag = w.img_flag;
+    if ((stages & 2) && per_image)
+        YP_LAUNCH(5, k_image_nms<YP_MODE_YOLOV3>, dim3(n_sets * p->batch), dim3(kImgThreads), 0, st, s);
     if (stages & 2)
         YP_LAUNCH(1, k_segment_nms<YP_MODE_YOLOV3>, dim3(n_seg), dim3(kSegThreads), 0, st, s);
     if ((stages & 2) && dense) {
@@ -3040,7 +3056,8 @@ int yp_profile_stop_ex(double *ms, int *calls)
         }
     *calls = g_prof.calls;
     // averages per CALL (a kernel a call did not launch counts as zero time)
-    for (int k = 0; k < kProfKernels; ++k) ms[k] = g_prof.calls ? acc[k] / g_prof.calls : 0.0;
+    acc[1] += acc[5];
+    for (int k = 0; k < kProfReported; ++k) ms[k] = g_prof.calls ? acc[k] / g_prof.calls : 0.0;
     for (int i = 0; i < kProfEvents * g_prof.max_calls; ++i) (void)hipEventDestroy(g_prof.ev[i]);
     delete[] g_prof.ev;
     delete[] g_prof.launched;
@@ -3053,7 +3070,7 @@ int yp_profile_stop_ex(double *ms, int *calls)
 int yp_profile_stop(double *front_ms, double *nms_ms, double *gather_ms, int *calls)
 {
     if (!front_ms || !nms_ms || !gather_ms) return YP_ERR_ARG;
-    double ms[kProfKernels];
+    double ms[kProfReported];
     const int rc = yp_profile_stop_ex(ms, calls);
     if (rc != YP_OK) return rc;
     *front_ms = ms[0];

@@ -1,0 +1,424 @@
+// yp_image.h -- greedy NMS of a WHOLE IMAGE by one workgroup (YOLOv3 mode: one segment per class).
+// Included by yolopost.hip inside its anonymous namespace (it uses that file's wave helpers,
+// SegArgs and yp_math.h).
+//
+// k_segment_nms gives every (image, class) segment a workgroup of its own, and every one of them
+// scans all candidate tiles of the image to find its class.  For images with a few hundred to a
+// couple of thousand candidates that scan, the fixed costs of a workgroup and the idle ends of its
+// loops are most of the work.  Here one workgroup takes the image:
+//
+//   gather   the image's tiles are read ONCE; a candidate reserves a place in its class's region
+//            of an LDS key pool with an LDS atomic (any order: the keys are sorted next);
+//   sort     rank sort inside every class, one task per 64 elements, tasks dealt to the waves;
+//   boxes    one trip to memory for the sorted boxes of all classes;
+//   pairs    the triangular suppression bitmask of every class (word w of column j holds the rows
+//            64w..64w+63 that precede j and suppress it), cut into units of four columns that
+//            are shared out evenly over the waves whatever the classes' sizes; two columns are
+//            tested per pass with packed binary32 arithmetic (v_pk_add_f32 / v_pk_mul_f32 do two
+//            operations per lane and instruction; every operation is the one yp_suppress_pretest
+//            performs, so the verdicts are the same bits);
+//   sweep    one wave per class walks its mask with the fixed-point iteration of k_segment_nms,
+//            all classes at the same time, and writes the kept slots.
+//
+// Classes whose masks do not fit the pool together are handled in groups, one after the other.
+// An image that does not fit at all (more than kImgCap candidates, a class beyond its region, a
+// box with x2 < x1 or a non-finite area) is flagged in img_flag and left to k_segment_nms, which
+// runs after this kernel and skips the images this kernel finished.  Outputs are exactly the
+// arrays k_segment_nms writes (kept_slot, seg_kept, seg_cand, seg_region, seg_pairs, seg_ties).
+#pragma once
+
+constexpr int kImgThreads = 512;
+constexpr int kImgWaves = kImgThreads / 64;
+constexpr int kImgMaxClasses = 32;            // classes an image may have on this path
+constexpr int kImgMaxTiles = 256;             // candidate tiles per image beyond which it is not tried
+constexpr int kImgCap = 1728;                 // candidates of an image
+constexpr int kImgPool = 4096;                // 64-bit words: gathered keys, later mask words
+constexpr int kImgStrips = kImgMaxClasses * kSmallWords;   // strip t = (class t / 8, row word t % 8)
+constexpr int kImgUnit = 4;                   // columns per unit of the pair loop
+static_assert(kImgStrips <= kImgThreads, "one thread per strip");
+static_assert(kSmallWords == 8, "strip index arithmetic");
+static_assert(kMaskWords <= kImgPool, "the mask of the largest class fits the pool");
+
+// two binary32 values that are added and multiplied together (one packed instruction on gfx950)
+#if defined(__clang__)
+typedef float yp_f2 __attribute__((ext_vector_type(2)));
+#else
+typedef float yp_f2 __attribute__((vector_size(8)));
+#endif
+
+// dst (one value per lane) takes the wave-uniform value val in lane l (a literal) and keeps the
+// rest.  (The CPU emulation the tests run these kernels under defines the macro itself.)
+#ifndef YP_WRITELANE
+#define YP_WRITELANE(dst, val, l) asm("v_writelane_b32 %0, %1, " #l : "+v"(dst) : "s"(val))
+#endif
+
+// Prefix record of a strip, four running sums packed into 64 bits: units of the pair loop (17
+// bits), mask words (19), candidates (16; counted at a class's first strip) and non-empty strips
+// (10).  512 strips of at most 128 units, 512 words and 513 candidates fit.
+__device__ __forceinline__ u64 img_pack(int units, int words, int cand, int tasks)
+{
+    return (u64)(unsigned)units | ((u64)(unsigned)words << 17) | ((u64)(unsigned)cand << 36) |
+           ((u64)(unsigned)tasks << 52);
+}
+__device__ __forceinline__ int img_units(u64 p) { return (int)(p & 0x1ffffull); }
+__device__ __forceinline__ int img_words(u64 p) { return (int)((p >> 17) & 0x7ffffull); }
+__device__ __forceinline__ int img_cand(u64 p) { return (int)((p >> 36) & 0xffffull); }
+__device__ __forceinline__ int img_tasks(u64 p) { return (int)(p >> 52); }
+
+__device__ __forceinline__ u64 wave_inclusive_scan64(u64 v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u64 t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// Two columns a, b (uniform over the wave) against one row per lane.  was / wbs: bit l set when
+// lane l's row suppresses the column.  The arithmetic is yp_suppress_pretest's for boxes whose
+// union is known to be positive (x2 >= x1, y2 >= y1, finite areas: checked when the boxes were
+// loaded) and a threshold inside the guard-band range; rows in ca_rows / cb_rows whose quotient
+// the bands leave undecided take the exact divide-and-compare and are counted as ties.
+template <int MODE>
+__device__ __forceinline__ void img_pair2(const float4 &ri, float ai, const float4 &ca,
+                                          const float4 &cb, float aa, float ab, const YpThr &thr,
+                                          u64 ca_rows, u64 cb_rows, u64 &was, u64 &wbs,
+                                          unsigned int &ties)
+{
+    const float plus1 = MODE == YP_MODE_YOLOV3 ? 1.0f : 0.0f;
+    const yp_f2 lo0 = {vmax(ri.x, ca.x), vmax(ri.x, cb.x)};
+    const yp_f2 lo1 = {vmax(ri.y, ca.y), vmax(ri.y, cb.y)};
+    const yp_f2 hi0 = {vmin(ri.z, ca.z), vmin(ri.z, cb.z)};
+    const yp_f2 hi1 = {vmin(ri.w, ca.w), vmin(ri.w, cb.w)};
+    yp_f2 d0 = hi0 - lo0;
+    yp_f2 d1 = hi1 - lo1;
+    d0 = d0 + plus1;
+    d1 = d1 + plus1;
+    d0[0] = vmax(d0[0], 0.0f);
+    d0[1] = vmax(d0[1], 0.0f);
+    d1[0] = vmax(d1[0], 0.0f);
+    d1[1] = vmax(d1[1], 0.0f);
+    const yp_f2 inter = d0 * d1;
+    const yp_f2 aj = {aa, ab};
+    yp_f2 uni = ai + aj;
+    uni = uni - inter;
+    const yp_f2 t_hi = uni * thr.hi;
+    const yp_f2 t_lo = uni * thr.lo;
+    u64 ya = __ballot(inter[0] > t_hi[0]);
+    u64 yb = __ballot(inter[1] > t_hi[1]);
+    const u64 na = __ballot(inter[0] < t_lo[0]);
+    const u64 nb = __ballot(inter[1] < t_lo[1]);
+    const u64 ua = ~(ya | na) & ca_rows;
+    const u64 ub = ~(yb | nb) & cb_rows;
+    if ((ua | ub) != 0ull) {   // rare: some quotient sits within 2^-20 of the threshold
+        const int lane = threadIdx.x & 63;
+        const YpPrep pi = {ri.x, ri.y, ri.z, ri.w, ai};
+        const YpPrep pa = {ca.x, ca.y, ca.z, ca.w, aa};
+        const YpPrep pb = {cb.x, cb.y, cb.z, cb.w, ab};
+        const bool ea = ((ua >> lane) & 1ull) && yp_suppresses_exact<MODE>(pi, pa, thr.thr);
+        const bool eb = ((ub >> lane) & 1ull) && yp_suppresses_exact<MODE>(pi, pb, thr.thr);
+        const u64 xa = __ballot(ea);
+        const u64 xb = __ballot(eb);
+        ya = (ya & ~ua) | xa;
+        yb = (yb & ~ub) | xb;
+        ties += (unsigned int)(__popcll(ua) + __popcll(ub));
+    }
+    was = ya & ca_rows;
+    wbs = yb & cb_rows;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
+{
+    __shared__ __align__(16) u64 s_pool[kImgPool];
+    __shared__ __align__(16) float4 s_box[kImgCap + 8];   // (+8: the last unit of a class may read on)
+    __shared__ float s_area[kImgCap + 8];
+    __shared__ int s_slot[kImgCap];
+    __shared__ u64 s_pref[kImgStrips + 1];     // packed sums over the strips before strip t
+    __shared__ u64 s_wsum[kImgWaves];
+    __shared__ int s_tasks[kImgStrips];        // the non-empty strips
+    __shared__ int s_cnt[kImgMaxClasses];      // candidates per class
+    __shared__ unsigned int s_tiesc[kImgMaxClasses];
+    __shared__ int s_flag;                     // the image is left to k_segment_nms
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int b = blockIdx.x;
+    const int C = s.C, tpi = s.tpi, ts = s.ts;
+    const size_t ibase = (size_t)b * s.spi;
+    const int *tcount = s.tile_count + (size_t)b * tpi;
+    // class c gathers into pool words [c * cs, c * cs + cc); the 8 words behind its keys are padding
+    const int cs = (kImgPool / C) & ~7;
+    const int cc = cs - 8 < kSmallCap ? cs - 8 : kSmallCap;
+
+    if (tid < kImgMaxClasses) {
+        s_cnt[tid] = 0;
+        s_tiesc[tid] = 0u;
+    }
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+
+    // ---- gather: wave w reads tiles w, w + 8, ... four at a time; lane r looks at candidate r
+    // of each (count, key and class are requested together, so a round is one trip to memory)
+    {
+        constexpr int kGatherTiles = 4;
+        auto place = [&](bool valid, float kf, int cl, int slot) {
+            if (valid) {
+                const int pos = atomicAdd(&s_cnt[cl], 1);
+                if (pos < cc)
+                    s_pool[cl * cs + pos] = ((u64)(~yp_float_order_bits(kf)) << 32) | (u64)(unsigned int)slot;
+            }
+        };
+        for (int t0 = wv; t0 < tpi; t0 += kImgWaves * kGatherTiles) {
+            int cnt[kGatherTiles], cl[kGatherTiles];
+            float kf[kGatherTiles];
+#pragma unroll
+            for (int u = 0; u < kGatherTiles; ++u) {
+                const int t = t0 + u * kImgWaves;
+                const int tile = t < tpi ? t : tpi - 1;
+                const int slot = tile * ts + lane;
+                cnt[u] = t < tpi ? tcount[tile] : 0;
+                kf[u] = s.cand_key[ibase + slot];
+                cl[u] = s.cand_cls[ibase + slot];
+            }
+#pragma unroll
+            for (int u = 0; u < kGatherTiles; ++u)
+                place(lane < cnt[u], kf[u], cl[u], (t0 + u * kImgWaves) * ts + lane);
+            // tiles with more than 64 candidates (rare): the rest, 64 at a time
+#pragma unroll
+            for (int u = 0; u < kGatherTiles; ++u) {
+                for (int r0 = 64; r0 < cnt[u]; r0 += 64) {
+                    const int r = r0 + lane;
+                    const int slot = (t0 + u * kImgWaves) * ts + (r < cnt[u] ? r : 0);
+                    place(r < cnt[u], s.cand_key[ibase + slot], s.cand_cls[ibase + slot], slot);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- strip table: thread t <-> strip (class t / 8, row word t % 8); a strip holds the
+    // columns 64w .. K_c - 1 of its class against the rows 64w .. 64w + 63
+    {
+        u64 v = 0ull;
+        int ncol = 0;
+        if (tid < kImgStrips) {
+            const int c = tid >> 3, w = tid & 7;
+            int kc = c < C ? s_cnt[c] : 0;
+            if (kc > cc) {
+                atomicOr(&s_flag, 1);
+                kc = cc;
+            }
+            ncol = kc - (w << 6);
+            if (ncol > 0) v = img_pack((ncol + kImgUnit - 1) / kImgUnit, ncol, w == 0 ? kc : 0, 1);
+            if (w == 0)   // padding for the rank sort, which reads its keys eight at a time
+                for (int i = kc; i < ((kc + 7) & ~7); ++i) s_pool[c * cs + i] = ~0ull;
+        }
+        const u64 incl = wave_inclusive_scan64(v, lane);
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        u64 woff = 0ull;
+        for (int w = 0; w < kImgWaves; ++w) woff += w < wave ? s_wsum[w] : 0ull;
+        const u64 excl = woff + incl - v;
+        if (tid < kImgStrips) {
+            s_pref[tid] = excl;
+            if (ncol > 0) s_tasks[img_tasks(excl)] = tid;
+            if (tid == kImgStrips - 1) s_pref[kImgStrips] = excl + v;
+        }
+    }
+    __syncthreads();
+    const u64 p_all = s_pref[kImgStrips];
+    const int k_img = img_cand(p_all);
+    if (s_flag != 0 || k_img > kImgCap) {   // (uniform) does not fit: k_segment_nms takes the image
+        if (tid == 0) s.img_flag[b] = 1;
+        return;
+    }
+    const int max_out = s.max_out > 0 ? s.max_out : 0x7fffffff;
+    const YpThr thr = yp_make_thr(s.thr);
+
+    // ---- rank sort inside every class: a task is 64 elements of one class against all its keys
+    {
+        const int n_tasks = img_tasks(p_all);
+        for (int k = wv; k < n_tasks; k += kImgWaves) {
+            const int t = __builtin_amdgcn_readfirstlane(s_tasks[k]);
+            const int c = t >> 3, w = t & 7;
+            const int kc = __builtin_amdgcn_readfirstlane(s_cnt[c]);
+            const int base = img_cand(s_pref[c << 3]);
+            const u64 *in = s_pool + c * cs;
+            const int e = (w << 6) + lane;
+            const u64 mine = e < kc ? in[e] : 0ull;
+            const ulonglong2 *in2 = reinterpret_cast<const ulonglong2 *>(in);
+            const int kp = (kc + 7) & ~7;
+            int rank = 0;
+            for (int j = 0; j < kp; j += 8) {
+                const ulonglong2 q0 = in2[j >> 1], q1 = in2[(j >> 1) + 1], q2 = in2[(j >> 1) + 2],
+                                 q3 = in2[(j >> 1) + 3];
+                rank += (q0.x < mine) + (q0.y < mine) + (q1.x < mine) + (q1.y < mine);
+                rank += (q2.x < mine) + (q2.y < mine) + (q3.x < mine) + (q3.y < mine);
+            }
+            if (e < kc) s_slot[base + rank] = (int)(unsigned int)(mine & 0xffffffffull);
+        }
+    }
+    __syncthreads();
+
+    // ---- the sorted boxes of all classes, prepared for the pair tests; the packed test needs
+    // x2 >= x1, y2 >= y1 and a finite area (then every union is >= 1)
+    {
+        bool safe = true;
+        for (int i = tid; i < k_img + 8; i += kImgThreads) {
+            float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+            float area = 1.0f;
+            if (i < k_img) {
+                const float4 raw = s.cand_box[ibase + s_slot[i]];
+                const YpBox q = {raw.x, raw.y, raw.z, raw.w};
+                const YpPrep pp = yp_prep<MODE>(q);
+                bx = make_float4(pp.lo0, pp.lo1, pp.hi0, pp.hi1);
+                area = pp.area;
+                // (comparisons that a NaN fails)
+                safe = safe && (pp.hi0 >= pp.lo0) && (pp.hi1 >= pp.lo1) && (area < 1e30f);
+            }
+            s_box[i] = bx;
+            s_area[i] = area;
+        }
+        if (!safe) atomicOr(&s_flag, 1);
+    }
+    __syncthreads();
+    if (s_flag != 0) {
+        if (tid == 0) s.img_flag[b] = 1;
+        return;
+    }
+    if (tid == 0) s.img_flag[b] = 0;
+
+    // ---- groups of consecutive classes whose masks fit the pool together
+    for (int g0 = 0; g0 < C;) {
+        const u64 p0 = s_pref[g0 << 3];
+        int g1 = g0 + 1;
+        while (g1 < C && img_words(s_pref[(g1 + 1) << 3]) - img_words(p0) <= kImgPool) ++g1;
+        const u64 p1 = s_pref[g1 << 3];
+        const int m0 = img_words(p0);
+
+        // -- pairs: the group's units in equal contiguous shares, one per wave
+        {
+            const int u_first = img_units(p0), n_units = img_units(p1) - u_first;
+            int u = u_first + (int)((long long)n_units * wv / kImgWaves);
+            const int u_hi = u_first + (int)((long long)n_units * (wv + 1) / kImgWaves);
+            unsigned int ties = 0u;
+            int ties_class = -1;
+            if (u < u_hi) {
+                // the last strip whose prefix does not exceed u (empty strips share a prefix with
+                // their successor, so the search lands on the one that holds the unit)
+                int lo = g0 << 3, hi = g1 << 3;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (img_units(s_pref[mid]) <= u) lo = mid;
+                    else hi = mid;
+                }
+                int t = lo;
+                while (u < u_hi) {
+                    while (img_units(s_pref[t + 1]) <= u) ++t;
+                    t = __builtin_amdgcn_readfirstlane(t);
+                    const int c = t >> 3, w = t & 7;
+                    const u64 pt = s_pref[t];
+                    const int kc = __builtin_amdgcn_readfirstlane(s_cnt[c]);
+                    const int bs = __builtin_amdgcn_readfirstlane(img_cand(s_pref[c << 3]));
+                    const int ub = __builtin_amdgcn_readfirstlane(img_units(pt));
+                    int ue = __builtin_amdgcn_readfirstlane(img_units(s_pref[t + 1]));
+                    ue = ue < u_hi ? ue : u_hi;
+                    u64 *cw = s_pool + (img_words(pt) - m0);   // cw[j - 64w], j >= 64w
+                    if (ties_class != c) {
+                        if (ties_class >= 0 && ties != 0u && lane == 0) atomicAdd(&s_tiesc[ties_class], ties);
+                        ties = 0u;
+                        ties_class = c;
+                    }
+                    const int i = (w << 6) + lane;
+                    const float4 ri = s_box[bs + (i < kc ? i : kc - 1)];
+                    const float ai = s_area[bs + (i < kc ? i : kc - 1)];
+                    const int n_rows = kc - (w << 6);
+                    const u64 rows_valid = n_rows >= 64 ? ~0ull : lanes_below(n_rows);
+                    for (; u < ue; ++u) {
+                        const int jr = kImgUnit * (u - ub);         // column relative to the strip
+                        const float4 *cb4 = s_box + bs + (w << 6) + jr;
+                        const float *ab4 = s_area + bs + (w << 6) + jr;
+                        u64 word[kImgUnit];
+#pragma unroll
+                        for (int q = 0; q < kImgUnit; q += 2) {
+                            // rows of this word that precede the column, none for a column past the class
+                            const int ja = jr + q, jb = jr + q + 1;
+                            const u64 ra = ja >= n_rows ? 0ull : (ja >= 64 ? rows_valid : lanes_below(ja));
+                            const u64 rb = jb >= n_rows ? 0ull : (jb >= 64 ? rows_valid : lanes_below(jb));
+                            const float4 ca = cb4[q], cb = cb4[q + 1];
+                            img_pair2<MODE>(ri, ai, ca, cb, ab4[q], ab4[q + 1], thr, ra, rb, word[q],
+                                            word[q + 1], ties);
+                        }
+                        // lane q stores the word of column q: one store instead of four (the
+                        // words are uniform over the wave; v_writelane puts one into one lane)
+                        int mlo = 0, mhi = 0;
+                        static_assert(kImgUnit == 4, "one YP_WRITELANE pair per column of a unit");
+                        YP_WRITELANE(mlo, (int)(unsigned int)word[0], 0);
+                        YP_WRITELANE(mhi, (int)(unsigned int)(word[0] >> 32), 0);
+                        YP_WRITELANE(mlo, (int)(unsigned int)word[1], 1);
+                        YP_WRITELANE(mhi, (int)(unsigned int)(word[1] >> 32), 1);
+                        YP_WRITELANE(mlo, (int)(unsigned int)word[2], 2);
+                        YP_WRITELANE(mhi, (int)(unsigned int)(word[2] >> 32), 2);
+                        YP_WRITELANE(mlo, (int)(unsigned int)word[3], 3);
+                        YP_WRITELANE(mhi, (int)(unsigned int)(word[3] >> 32), 3);
+                        if (lane < kImgUnit && jr + lane < n_rows)
+                            cw[jr + lane] = ((u64)(unsigned int)mhi << 32) | (u64)(unsigned int)mlo;
+                    }
+                }
+                if (ties_class >= 0 && ties != 0u && lane == 0) atomicAdd(&s_tiesc[ties_class], ties);
+            }
+        }
+        __syncthreads();
+
+        // -- sweep: one wave per class of the group, pure bit operations on the mask
+        for (int c = g0 + wv; c < g1; c += kImgWaves) {
+            const int kc = s_cnt[c];
+            const int bs = img_cand(s_pref[c << 3]);
+            const int nwords = (kc + 63) >> 6;
+            const size_t reg = ibase + bs;
+            int nkept = 0;
+            u64 keptw[kSmallWords];
+#pragma unroll
+            for (int w = 0; w < kSmallWords; ++w) keptw[w] = 0ull;
+#pragma unroll
+            for (int cwd = 0; cwd < kSmallWords; ++cwd) {
+                if (cwd < nwords && nkept < max_out) {
+                    const int j = (cwd << 6) + lane;
+                    const int jj = j < kc ? j : (cwd << 6);
+                    bool alive = j < kc;
+#pragma unroll
+                    for (int w = 0; w < cwd; ++w)
+                        alive = alive && (s_pool[img_words(s_pref[(c << 3) + w]) - m0 + jj - (w << 6)] & keptw[w]) == 0ull;
+                    const u64 mycol = (j < kc) ? s_pool[img_words(s_pref[(c << 3) + cwd]) - m0 + jj - (cwd << 6)] : 0ull;
+                    // greedy keep set of the chunk as the fixed point of
+                    // keep[i] = alive[i] && no kept earlier row of the chunk suppresses i
+                    u64 keep = __ballot(alive);
+                    for (int it = 0; it < 66; ++it) {
+                        const u64 nk = __ballot(alive && (mycol & keep) == 0ull);
+                        if (nk == keep) break;
+                        keep = nk;
+                    }
+                    const int room = max_out - nkept;
+                    if (__popcll(keep) > room)
+                        keep = __ballot(((keep >> lane) & 1ull) && __popcll(keep & lanes_below(lane)) < room);
+                    keptw[cwd] = keep;
+                    if ((keep >> lane) & 1ull)
+                        s.kept_slot[reg + nkept + __popcll(keep & lanes_below(lane))] = s_slot[bs + j];
+                    nkept += __popcll(keep);
+                }
+            }
+            if (lane == 0) {
+                const int seg = b * C + c;
+                s.seg_cand[seg] = kc;
+                s.seg_region[seg] = bs;
+                s.seg_kept[seg] = nkept;
+                s.seg_pairs[seg] = (unsigned int)((long long)kc * (kc - 1) / 2);
+                s.seg_ties[seg] = s_tiesc[c];
+            }
+        }
+        g0 = g1;
+        if (g0 < C) __syncthreads();   // the next group's masks overwrite the pool
+    }
+}

@@ -420,6 +420,9 @@ EMUL_OWN inline T first_lane(T v, int site)
 // the lanes that take part.
 #define __builtin_amdgcn_readlane(v, l) emul::read_lane((v), (int)(l), EMUL_SITE)
 #define __builtin_amdgcn_readfirstlane(v) emul::first_lane((v), EMUL_SITE)
+// v_writelane_b32 (inline assembly on the device): a value that is uniform over the wave goes into
+// ONE lane of a register
+#define YP_WRITELANE(dst, val, l) ((dst) = (emul::cur->lane == (l)) ? (val) : (dst))
 #define __builtin_amdgcn_wave_barrier() ((void)emul::park(emul::kWaveBarrier, EMUL_SITE, 0))
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
