@@ -157,8 +157,8 @@ struct SegArgs {
 #define STAMP(k)                                                                        \
     do {                                                                                \
         if (threadIdx.x == 0 && s.dbg) {                                                \
-            s.dbg[(size_t)blockIdx.x * 32 + (k)] = wall_clock64();                      \
-            s.dbg[(size_t)blockIdx.x * 32 + 16 + (k)] = clock64();                      \
+            s.dbg[(size_t)stamp_block * 32 + (k)] = wall_clock64();                  \
+            s.dbg[(size_t)stamp_block * 32 + 16 + (k)] = clock64();                  \
         }                                                                               \
     } while (0)
 #else
@@ -1375,10 +1375,9 @@ template <int MODE>
 #define YP_NMS_MIN_WAVES 6
 #define YP_NMS_MAX_WAVES 6
 #endif
-__global__ __launch_bounds__(kSegThreads)
-__attribute__((amdgpu_waves_per_eu(YP_NMS_MIN_WAVES, YP_NMS_MAX_WAVES)))
-void k_segment_nms(SegArgs s)
+__device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vblk, const int nblk)
 {
+    [[maybe_unused]] const int stamp_block = vblk;   // (diagnostic builds)
     // s_raw: sort keys of segments above kSmallCap (bitonic sort, up to kSortCap keys); for
     // small segments the triangular pairwise suppression bitmask.
     // s_small: [0, 8(cap+8)) gathered keys, later the sorted slot ids and box areas;
@@ -1399,7 +1398,7 @@ void k_segment_nms(SegArgs s)
     // bijection of workgroups to segments is correct.)
     int seg;
     {
-        const int nblk = (int)gridDim.x, x = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+        const int x = vblk & 7, k = vblk >> 3;
         const int per = nblk >> 3, rem = nblk & 7;
         seg = x < rem ? x * (per + 1) + k : rem * (per + 1) + (x - rem) * per + k;
     }
@@ -2087,7 +2086,7 @@ void k_segment_nms(SegArgs s)
         const bool prune = thr.fast && (MODE == YP_MODE_REFERENCE || allpos);
         nkept = nms_chunks<MODE>(gbox, grem, K, thr, max_out, s_chunk, xraw, xidx, prune, pairs, ties,
 #ifdef YP_STAMPS
-                                 s.dbg ? s.dbg + (size_t)blockIdx.x * 32 : nullptr,
+                                 s.dbg ? s.dbg + (size_t)vblk * 32 : nullptr,
 #else
                                  nullptr,
 #endif
@@ -2112,6 +2111,16 @@ void k_segment_nms(SegArgs s)
     }
     STAMP(6);
 }
+
+// One workgroup per segment.
+template <int MODE>
+__global__ __launch_bounds__(kSegThreads)
+__attribute__((amdgpu_waves_per_eu(YP_NMS_MIN_WAVES, YP_NMS_MAX_WAVES)))
+void k_segment_nms(SegArgs s)
+{
+    segment_nms_body<MODE>(s, (int)blockIdx.x, (int)gridDim.x);
+}
+
 
 // --------------------------------------------------------------------- final row gather
 #ifndef YP_GATHER_THREADS
@@ -2157,6 +2166,71 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_rows(GatherArgs g)
         const long long d = (long long)prefix + k;
         if (d >= g.cap) break;
         const int slot = g.kept_slot[reg + k];
+        float4 bx = g.cand_box[ibase + slot];
+        if (g.rescale) {
+            bx.x = vmin(vmax((bx.x - g.pad_x) / g.scale, 0.0f), g.im_w);
+            bx.y = vmin(vmax((bx.y - g.pad_y) / g.scale, 0.0f), g.im_h);
+            bx.z = vmin(vmax((bx.z - g.pad_x) / g.scale, 0.0f), g.im_w);
+            bx.w = vmin(vmax((bx.w - g.pad_y) / g.scale, 0.0f), g.im_h);
+        }
+        float4 *o = reinterpret_cast<float4 *>(rows_out + d * 8);
+        o[0] = make_float4((float)(b_in_set + g.batch_offset), bx.x, bx.y, bx.z);
+        o[1] = make_float4(bx.w, g.cand_key[ibase + slot], g.cand_aux[ibase + slot], (float)c);
+    }
+}
+
+// The same with one workgroup per IMAGE (up to kGatherImgClasses classes): the rows of earlier
+// images of the set are summed once per image instead of once per segment, and the image's rows of
+// all classes are written by one flat loop, so a few hundred rows keep 256 threads busy.
+constexpr int kGatherImgClasses = 64;
+__global__ __launch_bounds__(kGatherThreads) void k_gather_image(GatherArgs g)
+{
+    __shared__ int s_part[kGatherThreads / 64];
+    __shared__ int s_pre[kGatherImgClasses + 1];   // kept rows of the image before class c
+    __shared__ int s_reg[kGatherImgClasses];       // where class c's kept slots start in the image's region
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, C = g.C;
+    const int bps = g.spset / C;                   // images per set
+    const int set = b / bps, b_in_set = b - set * bps;
+    const int seg0 = set * g.spset, segb = b * C;
+    int part = 0;
+    for (int i = seg0 + tid; i < segb; i += kGatherThreads) part += g.seg_kept[i];
+    part = wave_sum(part);
+    if (lane == 0) s_part[wave] = part;
+    if (wave == 0) {
+        const int nk = lane < C ? g.seg_kept[segb + lane] : 0;
+        const int incl = wave_inclusive_scan(nk, lane);
+        if (lane < C) {
+            s_pre[lane + 1] = incl;
+            s_reg[lane] = g.seg_region[segb + lane];
+        }
+        if (lane == 0) s_pre[0] = 0;
+        if (g.stats && lane < C) {   // (n_sets, 4, images per set, C)
+            int *st = g.stats + (size_t)set * 4 * g.spset + (segb - seg0) + lane;
+            st[0] = g.seg_cand[segb + lane];
+            st[g.spset] = nk;
+            st[2 * g.spset] = (int)g.seg_pairs[segb + lane];
+            st[3 * g.spset] = (int)g.seg_ties[segb + lane];
+        }
+    }
+    __syncthreads();
+    int prefix = 0;
+#pragma unroll
+    for (int w = 0; w < kGatherThreads / 64; ++w) prefix += s_part[w];
+    const int total = s_pre[C];
+    if (tid == 0 && b_in_set == bps - 1) g.out_count[set] = prefix + total;
+    const size_t ibase = (size_t)b * g.spi;
+    float *rows_out = g.out_rows + (size_t)set * g.set_stride;
+    for (int k = tid; k < total; k += kGatherThreads) {
+        const long long d = (long long)prefix + k;
+        if (d >= g.cap) break;
+        int c = 0, hi = C;   // the class whose rows hold position k: s_pre[c] <= k < s_pre[c + 1]
+        while (hi - c > 1) {
+            const int mid = (c + hi) >> 1;
+            if (k >= s_pre[mid]) c = mid;
+            else hi = mid;
+        }
+        const int slot = g.kept_slot[ibase + s_reg[c] + (k - s_pre[c])];
         float4 bx = g.cand_box[ibase + slot];
         if (g.rescale) {
             bx.x = vmin(vmax((bx.x - g.pad_x) / g.scale, 0.0f), g.im_w);
@@ -2635,7 +2709,10 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
     g.cap = cap;
     g.out_count = out_count;
     g.stats = stats;
-    if (stages & 4) YP_LAUNCH(2, k_gather_rows, dim3(n_seg), dim3(kGatherThreads), 0, st, g);
+    if ((stages & 4) && p->num_classes <= kGatherImgClasses)
+        YP_LAUNCH(2, k_gather_image, dim3(n_sets * p->batch), dim3(kGatherThreads), 0, st, g);
+    else if (stages & 4)
+        YP_LAUNCH(2, k_gather_rows, dim3(n_seg), dim3(kGatherThreads), 0, st, g);
     prof_next();
     return (int)hipGetLastError();
 }

@@ -21,13 +21,16 @@
 //            all classes at the same time, and writes the kept slots.
 //
 // Classes whose masks do not fit the pool together are handled in groups, one after the other.
-// An image that does not fit at all (more than kImgCap candidates, a class beyond its region, a
-// box with x2 < x1 or a non-finite area) is flagged in img_flag and left to k_segment_nms, which
+// An image that does not fit (more than kImgCap candidates, a class beyond its region, two equal
+// objectness values inside a class, a box with x2 < x1 or a non-finite area) is flagged in img_flag and left to k_segment_nms, which
 // runs after this kernel and skips the images this kernel finished.  Outputs are exactly the
 // arrays k_segment_nms writes (kept_slot, seg_kept, seg_cand, seg_region, seg_pairs, seg_ties).
 #pragma once
 
-constexpr int kImgThreads = 512;
+#ifndef YP_IMG_THREADS
+#define YP_IMG_THREADS 1024
+#endif
+constexpr int kImgThreads = YP_IMG_THREADS;
 constexpr int kImgWaves = kImgThreads / 64;
 constexpr int kImgMaxClasses = 32;            // classes an image may have on this path
 constexpr int kImgMaxTiles = 256;             // candidate tiles per image beyond which it is not tried
@@ -129,7 +132,11 @@ __device__ __forceinline__ void img_pair2(const float4 &ri, float ai, const floa
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
+__global__ __launch_bounds__(kImgThreads)
+#if YP_IMG_THREADS == 1024
+__attribute__((amdgpu_waves_per_eu(8, 8)))   // two workgroups per CU: at most 64 vector registers
+#endif
+void k_image_nms(SegArgs s)
 {
     __shared__ __align__(16) u64 s_pool[kImgPool];
     __shared__ __align__(16) float4 s_box[kImgCap + 8];   // (+8: the last unit of a class may read on)
@@ -145,18 +152,25 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int b = blockIdx.x;
+    [[maybe_unused]] const int stamp_block = b;   // (diagnostic builds)
     const int C = s.C, tpi = s.tpi, ts = s.ts;
     const size_t ibase = (size_t)b * s.spi;
     const int *tcount = s.tile_count + (size_t)b * tpi;
-    // class c gathers into pool words [c * cs, c * cs + cc); the 8 words behind its keys are padding
+    // The pool as 32-bit words: class c owns [2 c cs, 2 (c + 1) cs) -- cs sort keys (the order
+    // bits of the objectness, inverted: ascending key = descending objectness), then the cs slot
+    // ids that belong to them; at most cc candidates, the 8 keys behind them are padding.
     const int cs = (kImgPool / C) & ~7;
     const int cc = cs - 8 < kSmallCap ? cs - 8 : kSmallCap;
+    unsigned int *pool32 = reinterpret_cast<unsigned int *>(s_pool);
 
+    STAMP(0);
     if (tid < kImgMaxClasses) {
         s_cnt[tid] = 0;
         s_tiesc[tid] = 0u;
     }
     if (tid == 0) s_flag = 0;
+    // (a sorted position nobody writes keeps its -1: two candidates of a class had equal keys)
+    for (int i = tid; i < kImgCap; i += kImgThreads) s_slot[i] = -1;
     __syncthreads();
 
     // ---- gather: wave w reads tiles w, w + 8, ... four at a time; lane r looks at candidate r
@@ -166,8 +180,10 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
         auto place = [&](bool valid, float kf, int cl, int slot) {
             if (valid) {
                 const int pos = atomicAdd(&s_cnt[cl], 1);
-                if (pos < cc)
-                    s_pool[cl * cs + pos] = ((u64)(~yp_float_order_bits(kf)) << 32) | (u64)(unsigned int)slot;
+                if (pos < cc) {
+                    pool32[2 * cl * cs + pos] = ~yp_float_order_bits(kf);
+                    pool32[2 * cl * cs + cs + pos] = (unsigned int)slot;
+                }
             }
         };
         for (int t0 = wv; t0 < tpi; t0 += kImgWaves * kGatherTiles) {
@@ -197,6 +213,7 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
         }
     }
     __syncthreads();
+    STAMP(1);
 
     // ---- strip table: thread t <-> strip (class t / 8, row word t % 8); a strip holds the
     // columns 64w .. K_c - 1 of its class against the rows 64w .. 64w + 63
@@ -213,7 +230,7 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
             ncol = kc - (w << 6);
             if (ncol > 0) v = img_pack((ncol + kImgUnit - 1) / kImgUnit, ncol, w == 0 ? kc : 0, 1);
             if (w == 0)   // padding for the rank sort, which reads its keys eight at a time
-                for (int i = kc; i < ((kc + 7) & ~7); ++i) s_pool[c * cs + i] = ~0ull;
+                for (int i = kc; i < ((kc + 7) & ~7); ++i) pool32[2 * c * cs + i] = ~0u;
         }
         const u64 incl = wave_inclusive_scan64(v, lane);
         if (lane == 63) s_wsum[wave] = incl;
@@ -228,6 +245,7 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
         }
     }
     __syncthreads();
+    STAMP(2);
     const u64 p_all = s_pref[kImgStrips];
     const int k_img = img_cand(p_all);
     if (s_flag != 0 || k_img > kImgCap) {   // (uniform) does not fit: k_segment_nms takes the image
@@ -237,7 +255,10 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
     const int max_out = s.max_out > 0 ? s.max_out : 0x7fffffff;
     const YpThr thr = yp_make_thr(s.thr);
 
-    // ---- rank sort inside every class: a task is 64 elements of one class against all its keys
+    // ---- rank sort inside every class: a task is 64 elements of one class against all its keys.
+    // Only the 32 key bits are compared.  Equal objectness values inside a class (saturated
+    // sigmoids) would have to be ordered by slot; they give two elements the same rank instead,
+    // some position stays unwritten, and the image goes to k_segment_nms, which sorts 64-bit keys.
     {
         const int n_tasks = img_tasks(p_all);
         for (int k = wv; k < n_tasks; k += kImgWaves) {
@@ -245,22 +266,24 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
             const int c = t >> 3, w = t & 7;
             const int kc = __builtin_amdgcn_readfirstlane(s_cnt[c]);
             const int base = img_cand(s_pref[c << 3]);
-            const u64 *in = s_pool + c * cs;
+            const unsigned int *in = pool32 + 2 * c * cs;
             const int e = (w << 6) + lane;
-            const u64 mine = e < kc ? in[e] : 0ull;
-            const ulonglong2 *in2 = reinterpret_cast<const ulonglong2 *>(in);
+            const unsigned int mine = e < kc ? in[e] : 0u;
+            const int4 *in4 = reinterpret_cast<const int4 *>(in);
             const int kp = (kc + 7) & ~7;
             int rank = 0;
             for (int j = 0; j < kp; j += 8) {
-                const ulonglong2 q0 = in2[j >> 1], q1 = in2[(j >> 1) + 1], q2 = in2[(j >> 1) + 2],
-                                 q3 = in2[(j >> 1) + 3];
-                rank += (q0.x < mine) + (q0.y < mine) + (q1.x < mine) + (q1.y < mine);
-                rank += (q2.x < mine) + (q2.y < mine) + (q3.x < mine) + (q3.y < mine);
+                const int4 q0 = in4[j >> 2], q1 = in4[(j >> 2) + 1];
+                rank += ((unsigned int)q0.x < mine) + ((unsigned int)q0.y < mine) +
+                        ((unsigned int)q0.z < mine) + ((unsigned int)q0.w < mine);
+                rank += ((unsigned int)q1.x < mine) + ((unsigned int)q1.y < mine) +
+                        ((unsigned int)q1.z < mine) + ((unsigned int)q1.w < mine);
             }
-            if (e < kc) s_slot[base + rank] = (int)(unsigned int)(mine & 0xffffffffull);
+            if (e < kc) s_slot[base + rank] = (int)in[cs + e];
         }
     }
     __syncthreads();
+    STAMP(3);
 
     // ---- the sorted boxes of all classes, prepared for the pair tests; the packed test needs
     // x2 >= x1, y2 >= y1 and a finite area (then every union is >= 1)
@@ -270,7 +293,9 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
             float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
             float area = 1.0f;
             if (i < k_img) {
-                const float4 raw = s.cand_box[ibase + s_slot[i]];
+                const int slot = s_slot[i];
+                safe = safe && slot >= 0;
+                const float4 raw = s.cand_box[ibase + (slot >= 0 ? slot : 0)];
                 const YpBox q = {raw.x, raw.y, raw.z, raw.w};
                 const YpPrep pp = yp_prep<MODE>(q);
                 bx = make_float4(pp.lo0, pp.lo1, pp.hi0, pp.hi1);
@@ -289,6 +314,7 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
         return;
     }
     if (tid == 0) s.img_flag[b] = 0;
+    STAMP(4);
 
     // ---- groups of consecutive classes whose masks fit the pool together
     for (int g0 = 0; g0 < C;) {
@@ -338,8 +364,17 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
                     const u64 rows_valid = n_rows >= 64 ? ~0ull : lanes_below(n_rows);
                     for (; u < ue; ++u) {
                         const int jr = kImgUnit * (u - ub);         // column relative to the strip
-                        const float4 *cb4 = s_box + bs + (w << 6) + jr;
-                        const float *ab4 = s_area + bs + (w << 6) + jr;
+                        float4 col[kImgUnit];
+                        float car[kImgUnit];
+                        {
+                            const float4 *cb4 = s_box + bs + (w << 6) + jr;
+                            const float *ab4 = s_area + bs + (w << 6) + jr;
+#pragma unroll
+                            for (int q = 0; q < kImgUnit; ++q) {
+                                col[q] = cb4[q];
+                                car[q] = ab4[q];
+                            }
+                        }
                         u64 word[kImgUnit];
 #pragma unroll
                         for (int q = 0; q < kImgUnit; q += 2) {
@@ -347,9 +382,8 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
                             const int ja = jr + q, jb = jr + q + 1;
                             const u64 ra = ja >= n_rows ? 0ull : (ja >= 64 ? rows_valid : lanes_below(ja));
                             const u64 rb = jb >= n_rows ? 0ull : (jb >= 64 ? rows_valid : lanes_below(jb));
-                            const float4 ca = cb4[q], cb = cb4[q + 1];
-                            img_pair2<MODE>(ri, ai, ca, cb, ab4[q], ab4[q + 1], thr, ra, rb, word[q],
-                                            word[q + 1], ties);
+                            img_pair2<MODE>(ri, ai, col[q], col[q + 1], car[q], car[q + 1], thr, ra, rb,
+                                            word[q], word[q + 1], ties);
                         }
                         // lane q stores the word of column q: one store instead of four (the
                         // words are uniform over the wave; v_writelane puts one into one lane)
@@ -371,6 +405,7 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
             }
         }
         __syncthreads();
+        STAMP(5);
 
         // -- sweep: one wave per class of the group, pure bit operations on the mask
         for (int c = g0 + wv; c < g1; c += kImgWaves) {
@@ -421,4 +456,5 @@ __global__ __launch_bounds__(kImgThreads) void k_image_nms(SegArgs s)
         g0 = g1;
         if (g0 < C) __syncthreads();   // the next group's masks overwrite the pool
     }
+    STAMP(6);
 }

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Diagnostic: where the per-image NMS workgroups spend their time (in-kernel stamps).
+
+Build the diagnostic library first (make -C 2d_object_detection_amd/csrc stamps) and run
+    YOLOPOST_LIB=2d_object_detection_amd/libyolopost_stamps.so python tools/img_stamps.py
+Stamps are 100 MHz wall-clock ticks taken by thread 0 of every workgroup; the shipped
+library contains none of this."""
+import ctypes
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("2d_object_detection_amd")
+syn, util, _lib = pkg.synthetic, pkg.util, pkg._lib
+
+B = int(os.environ.get("B", 64))
+SETS = int(os.environ.get("SETS", 8))
+inp = int(os.environ.get("INP", "416"))
+CONF = float(os.environ.get("CONF", 0.5))
+dev = torch.device("cuda:0")
+sets = [[h.to(dev) for h in syn.make_heads(B, inp, 5, seed=1 + k)] for k in range(SETS)]
+eng = util.YoloV3PostMulti(SETS, B, inp, 5, CONF, 0.4, device=dev)
+nseg = SETS * B * 5
+dbg = torch.zeros((nseg, 32), dtype=torch.int64, device=dev)
+L = _lib.load()
+L.yp_debug_set_stamps.argtypes = [ctypes.c_void_p]
+for _ in range(5):
+    eng.run(sets)
+L.yp_debug_set_stamps(dbg.data_ptr())
+eng.run(sets)
+torch.cuda.synchronize()
+L.yp_debug_set_stamps(None)
+n_img = SETS * B
+t = dbg.cpu().numpy()[:n_img].astype(np.float64) * 10.0 / 1000.0   # ticks of 10 ns -> us
+names = ["gather", "strips", "sort", "boxes", "pairs", "sweep"]
+t0 = t[:, 0].min()
+print("images %d; last start %.2f us, last end %.2f us (relative to the first start)"
+      % (n_img, (t[:, 0] - t0).max(), (t[:, 6] - t0).max()))
+for k, n in enumerate(names):
+    d = t[:, k + 1] - t[:, k]
+    print("%-8s mean %.2f us  max %.2f us" % (n, d.mean(), d.max()))
+print("workgroup total mean %.2f us max %.2f us" % ((t[:, 6] - t[:, 0]).mean(), (t[:, 6] - t[:, 0]).max()))
