@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "yolopost.h"
@@ -2614,6 +2615,17 @@ inline void prof_next()
             hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                       \
     } while (0)
 
+// Smallest launch (images) that takes the per-image NMS kernel: kImgMinImages unless the
+// environment says otherwise (read at every call: a test may change it between calls).
+int image_path_min_images()
+{
+    const char *e = getenv("YP_IMG_MIN_IMAGES");
+    if (e == nullptr || *e == 0) return kImgMinImages;
+    char *end = nullptr;
+    const long v = strtol(e, &end, 10);
+    return (end == e || v < 1) ? kImgMinImages : (v > 0x7fffffffl ? 0x7fffffff : (int)v);
+}
+
 // Segment NMS + final gather of the YOLOv3 path (shared by the heads and rows entries).
 int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tpi, int ts,
               float *out_rows, long long cap, int32_t *out_count, int32_t *stats, hipStream_t st,
@@ -2635,7 +2647,7 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
     // Images of moderate size are finished by one workgroup each (k_image_nms); that kernel flags
     // the images it cannot take, and k_segment_nms, launched behind it, only works on those.
     const bool per_image = p->num_classes <= kImgMaxClasses && tpi <= kImgMaxTiles &&
-                           yp_make_thr(p->nms_thr).fast;
+                           n_sets * p->batch >= image_path_min_images() && yp_make_thr(p->nms_thr).fast;
     if (per_image) s.img_flag = w.img_flag;
     if ((stages & 2) && per_image)
         YP_LAUNCH(5, k_image_nms<YP_MODE_YOLOV3>, dim3(n_sets * p->batch), dim3(kImgThreads), 0, st, s);

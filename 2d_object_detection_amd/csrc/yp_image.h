@@ -11,12 +11,16 @@
 //            of an LDS key pool with an LDS atomic (any order: the keys are sorted next);
 //   sort     rank sort inside every class, one task per 64 elements, tasks dealt to the waves;
 //   boxes    one trip to memory for the sorted boxes of all classes;
-//   pairs    the triangular suppression bitmask of every class (word w of column j holds the rows
-//            64w..64w+63 that precede j and suppress it), cut into units of four columns that
-//            are shared out evenly over the waves whatever the classes' sizes; two columns are
-//            tested per pass with packed binary32 arithmetic (v_pk_add_f32 / v_pk_mul_f32 do two
-//            operations per lane and instruction; every operation is the one yp_suppress_pretest
-//            performs, so the verdicts are the same bits);
+//   pairs    the triangular suppression bitmask of every class, in strips of 32 rows: half-word h
+//            of column j holds the rows 32h..32h+31 that precede j and suppress it.  A strip's
+//            columns are cut into units of eight; both halves of a wave hold the strip's 32 rows,
+//            the lower half tests the first four columns of a unit and the upper half the other
+//            four (a 64-row strip would idle half its lanes over the 64 columns of its diagonal
+//            block, a 32-row strip over 32).  The units of all classes are shared out evenly
+//            over the waves whatever the classes' sizes; two columns are tested per pass with
+//            packed binary32 arithmetic (v_pk_add_f32 / v_pk_mul_f32 do two operations per lane
+//            and instruction; every operation is the one yp_suppress_pretest performs, so the
+//            verdicts are the same bits);
 //   sweep    one wave per class walks its mask with the fixed-point iteration of k_segment_nms,
 //            all classes at the same time, and writes the kept slots.
 //
@@ -34,13 +38,23 @@ constexpr int kImgThreads = YP_IMG_THREADS;
 constexpr int kImgWaves = kImgThreads / 64;
 constexpr int kImgMaxClasses = 32;            // classes an image may have on this path
 constexpr int kImgMaxTiles = 256;             // candidate tiles per image beyond which it is not tried
+// Launches with fewer images stay with k_segment_nms: one workgroup per image needs about 27 us
+// whatever the launch size, so it pays once the images fill the GPU (measured on an MI355X: 256
+// images 38 us against 32 us for the segment kernel alone, 512 images 40 against 55; with several
+// launches in flight the smaller instruction count of this kernel wins from 256 images on).
+// The environment variable YP_IMG_MIN_IMAGES overrides it (the tests use 1 and a huge value to
+// run every case on both paths).
+constexpr int kImgMinImages = 256;
 constexpr int kImgCap = 1728;                 // candidates of an image
 constexpr int kImgPool = 4096;                // 64-bit words: gathered keys, later mask words
-constexpr int kImgStrips = kImgMaxClasses * kSmallWords;   // strip t = (class t / 8, row word t % 8)
-constexpr int kImgUnit = 4;                   // columns per unit of the pair loop
+constexpr int kImgHalves = 2 * kSmallWords;   // 32-row strips of the largest class
+constexpr int kImgStrips = kImgMaxClasses * kImgHalves;    // strip t = (class t / 16, row block t % 16)
+constexpr int kImgUnit = 8;                   // columns per unit of the pair loop (four per half wave)
 static_assert(kImgStrips <= kImgThreads, "one thread per strip");
-static_assert(kSmallWords == 8, "strip index arithmetic");
-static_assert(kMaskWords <= kImgPool, "the mask of the largest class fits the pool");
+static_assert(kImgHalves == 16, "strip index arithmetic");
+// (32-bit mask words of a class of kSmallCap candidates: sum over its strips of cap - 32 h)
+static_assert(kImgHalves * kSmallCap - 16 * kImgHalves * (kImgHalves - 1) <= 2 * kImgPool,
+              "the mask of the largest class fits the pool");
 
 // two binary32 values that are added and multiplied together (one packed instruction on gfx950)
 #if defined(__clang__)
@@ -56,8 +70,9 @@ typedef float yp_f2 __attribute__((vector_size(8)));
 #endif
 
 // Prefix record of a strip, four running sums packed into 64 bits: units of the pair loop (17
-// bits), mask words (19), candidates (16; counted at a class's first strip) and non-empty strips
-// (10).  512 strips of at most 128 units, 512 words and 513 candidates fit.
+// bits), 32-bit mask words (19), candidates (16; counted at a class's first strip) and sort tasks
+// (10; one per 64 candidates).  512 strips of at most 64 units and 512 words, 32 classes of at
+// most 513 candidates fit.
 __device__ __forceinline__ u64 img_pack(int units, int words, int cand, int tasks)
 {
     return (u64)(unsigned)units | ((u64)(unsigned)words << 17) | ((u64)(unsigned)cand << 36) |
@@ -144,7 +159,7 @@ void k_image_nms(SegArgs s)
     __shared__ int s_slot[kImgCap];
     __shared__ u64 s_pref[kImgStrips + 1];     // packed sums over the strips before strip t
     __shared__ u64 s_wsum[kImgWaves];
-    __shared__ int s_tasks[kImgStrips];        // the non-empty strips
+    __shared__ int s_tasks[kImgStrips / 2];    // the strips that start a sort task
     __shared__ int s_cnt[kImgMaxClasses];      // candidates per class
     __shared__ unsigned int s_tiesc[kImgMaxClasses];
     __shared__ int s_flag;                     // the image is left to k_segment_nms
@@ -215,21 +230,23 @@ void k_image_nms(SegArgs s)
     __syncthreads();
     STAMP(1);
 
-    // ---- strip table: thread t <-> strip (class t / 8, row word t % 8); a strip holds the
-    // columns 64w .. K_c - 1 of its class against the rows 64w .. 64w + 63
+    // ---- strip table: thread t <-> strip (class t / 16, row block t % 16); a strip holds the
+    // columns 32h .. K_c - 1 of its class against the rows 32h .. 32h + 31
     {
         u64 v = 0ull;
         int ncol = 0;
+        bool task = false;
         if (tid < kImgStrips) {
-            const int c = tid >> 3, w = tid & 7;
+            const int c = tid >> 4, h = tid & 15;
             int kc = c < C ? s_cnt[c] : 0;
             if (kc > cc) {
                 atomicOr(&s_flag, 1);
                 kc = cc;
             }
-            ncol = kc - (w << 6);
-            if (ncol > 0) v = img_pack((ncol + kImgUnit - 1) / kImgUnit, ncol, w == 0 ? kc : 0, 1);
-            if (w == 0)   // padding for the rank sort, which reads its keys eight at a time
+            ncol = kc - (h << 5);
+            task = ncol > 0 && (h & 1) == 0;   // (a sort task: 64 candidates from 32h on)
+            if (ncol > 0) v = img_pack((ncol + kImgUnit - 1) / kImgUnit, ncol, h == 0 ? kc : 0, task ? 1 : 0);
+            if (h == 0)   // padding for the rank sort, which reads its keys eight at a time
                 for (int i = kc; i < ((kc + 7) & ~7); ++i) pool32[2 * c * cs + i] = ~0u;
         }
         const u64 incl = wave_inclusive_scan64(v, lane);
@@ -240,7 +257,7 @@ void k_image_nms(SegArgs s)
         const u64 excl = woff + incl - v;
         if (tid < kImgStrips) {
             s_pref[tid] = excl;
-            if (ncol > 0) s_tasks[img_tasks(excl)] = tid;
+            if (task) s_tasks[img_tasks(excl)] = tid;
             if (tid == kImgStrips - 1) s_pref[kImgStrips] = excl + v;
         }
     }
@@ -263,9 +280,9 @@ void k_image_nms(SegArgs s)
         const int n_tasks = img_tasks(p_all);
         for (int k = wv; k < n_tasks; k += kImgWaves) {
             const int t = __builtin_amdgcn_readfirstlane(s_tasks[k]);
-            const int c = t >> 3, w = t & 7;
+            const int c = t >> 4, w = (t & 15) >> 1;
             const int kc = __builtin_amdgcn_readfirstlane(s_cnt[c]);
-            const int base = img_cand(s_pref[c << 3]);
+            const int base = img_cand(s_pref[c << 4]);
             const unsigned int *in = pool32 + 2 * c * cs;
             const int e = (w << 6) + lane;
             const unsigned int mine = e < kc ? in[e] : 0u;
@@ -318,10 +335,10 @@ void k_image_nms(SegArgs s)
 
     // ---- groups of consecutive classes whose masks fit the pool together
     for (int g0 = 0; g0 < C;) {
-        const u64 p0 = s_pref[g0 << 3];
+        const u64 p0 = s_pref[g0 << 4];
         int g1 = g0 + 1;
-        while (g1 < C && img_words(s_pref[(g1 + 1) << 3]) - img_words(p0) <= kImgPool) ++g1;
-        const u64 p1 = s_pref[g1 << 3];
+        while (g1 < C && img_words(s_pref[(g1 + 1) << 4]) - img_words(p0) <= 2 * kImgPool) ++g1;
+        const u64 p1 = s_pref[g1 << 4];
         const int m0 = img_words(p0);
 
         // -- pairs: the group's units in equal contiguous shares, one per wave
@@ -331,10 +348,11 @@ void k_image_nms(SegArgs s)
             const int u_hi = u_first + (int)((long long)n_units * (wv + 1) / kImgWaves);
             unsigned int ties = 0u;
             int ties_class = -1;
+            const int half = lane >> 5, hl = lane & 31;   // lower / upper half of the wave, lane inside it
             if (u < u_hi) {
                 // the last strip whose prefix does not exceed u (empty strips share a prefix with
                 // their successor, so the search lands on the one that holds the unit)
-                int lo = g0 << 3, hi = g1 << 3;
+                int lo = g0 << 4, hi = g1 << 4;
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
                     if (img_units(s_pref[mid]) <= u) lo = mid;
@@ -344,61 +362,72 @@ void k_image_nms(SegArgs s)
                 while (u < u_hi) {
                     while (img_units(s_pref[t + 1]) <= u) ++t;
                     t = __builtin_amdgcn_readfirstlane(t);
-                    const int c = t >> 3, w = t & 7;
+                    const int c = t >> 4, h = t & 15;
                     const u64 pt = s_pref[t];
                     const int kc = __builtin_amdgcn_readfirstlane(s_cnt[c]);
-                    const int bs = __builtin_amdgcn_readfirstlane(img_cand(s_pref[c << 3]));
+                    const int bs = __builtin_amdgcn_readfirstlane(img_cand(s_pref[c << 4]));
                     const int ub = __builtin_amdgcn_readfirstlane(img_units(pt));
                     int ue = __builtin_amdgcn_readfirstlane(img_units(s_pref[t + 1]));
                     ue = ue < u_hi ? ue : u_hi;
-                    u64 *cw = s_pool + (img_words(pt) - m0);   // cw[j - 64w], j >= 64w
+                    unsigned int *hw = pool32 + (img_words(pt) - m0);   // hw[j - 32h], j >= 32h
                     if (ties_class != c) {
                         if (ties_class >= 0 && ties != 0u && lane == 0) atomicAdd(&s_tiesc[ties_class], ties);
                         ties = 0u;
                         ties_class = c;
                     }
-                    const int i = (w << 6) + lane;
+                    // both halves of the wave hold the strip's rows; the upper half works four
+                    // columns ahead of the lower one
+                    const int i = (h << 5) + hl;
                     const float4 ri = s_box[bs + (i < kc ? i : kc - 1)];
                     const float ai = s_area[bs + (i < kc ? i : kc - 1)];
-                    const int n_rows = kc - (w << 6);
-                    const u64 rows_valid = n_rows >= 64 ? ~0ull : lanes_below(n_rows);
+                    const int n_rows = kc - (h << 5);           // rows, and columns, of the strip
+                    const unsigned int rows_valid = n_rows >= 32 ? ~0u : (1u << n_rows) - 1u;
+                    const float4 *cbase = s_box + bs + (h << 5) + 4 * half;
+                    const float *abase = s_area + bs + (h << 5) + 4 * half;
+                    // the rows of this strip that precede its column j (relative), none past the class
+                    auto rows_before = [&](int j) {
+                        return j >= n_rows ? 0u : (j >= 32 ? rows_valid : (1u << j) - 1u);
+                    };
                     for (; u < ue; ++u) {
-                        const int jr = kImgUnit * (u - ub);         // column relative to the strip
-                        float4 col[kImgUnit];
-                        float car[kImgUnit];
-                        {
-                            const float4 *cb4 = s_box + bs + (w << 6) + jr;
-                            const float *ab4 = s_area + bs + (w << 6) + jr;
+                        const int jr = kImgUnit * (u - ub);         // first column of the unit
+                        float4 col[4];
+                        float car[4];
 #pragma unroll
-                            for (int q = 0; q < kImgUnit; ++q) {
-                                col[q] = cb4[q];
-                                car[q] = ab4[q];
+                        for (int q = 0; q < 4; ++q) {
+                            col[q] = cbase[jr + q];
+                            car[q] = abase[jr + q];
+                        }
+                        u64 word[4];   // bits 0..31: column jr + q, bits 32..63: column jr + 4 + q
+                        if (jr >= 32 && jr + kImgUnit <= n_rows) {
+                            // past the diagonal block and inside the class: every row counts
+                            const u64 rv = (u64)rows_valid | ((u64)rows_valid << 32);
+#pragma unroll
+                            for (int q = 0; q < 4; q += 2)
+                                img_pair2<MODE>(ri, ai, col[q], col[q + 1], car[q], car[q + 1], thr, rv, rv,
+                                                word[q], word[q + 1], ties);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; q += 2) {
+                                const u64 ra = (u64)rows_before(jr + q) | ((u64)rows_before(jr + 4 + q) << 32);
+                                const u64 rb = (u64)rows_before(jr + q + 1) | ((u64)rows_before(jr + 5 + q) << 32);
+                                img_pair2<MODE>(ri, ai, col[q], col[q + 1], car[q], car[q + 1], thr, ra, rb,
+                                                word[q], word[q + 1], ties);
                             }
                         }
-                        u64 word[kImgUnit];
-#pragma unroll
-                        for (int q = 0; q < kImgUnit; q += 2) {
-                            // rows of this word that precede the column, none for a column past the class
-                            const int ja = jr + q, jb = jr + q + 1;
-                            const u64 ra = ja >= n_rows ? 0ull : (ja >= 64 ? rows_valid : lanes_below(ja));
-                            const u64 rb = jb >= n_rows ? 0ull : (jb >= 64 ? rows_valid : lanes_below(jb));
-                            img_pair2<MODE>(ri, ai, col[q], col[q + 1], car[q], car[q + 1], thr, ra, rb,
-                                            word[q], word[q + 1], ties);
-                        }
-                        // lane q stores the word of column q: one store instead of four (the
-                        // words are uniform over the wave; v_writelane puts one into one lane)
-                        int mlo = 0, mhi = 0;
-                        static_assert(kImgUnit == 4, "one YP_WRITELANE pair per column of a unit");
-                        YP_WRITELANE(mlo, (int)(unsigned int)word[0], 0);
-                        YP_WRITELANE(mhi, (int)(unsigned int)(word[0] >> 32), 0);
-                        YP_WRITELANE(mlo, (int)(unsigned int)word[1], 1);
-                        YP_WRITELANE(mhi, (int)(unsigned int)(word[1] >> 32), 1);
-                        YP_WRITELANE(mlo, (int)(unsigned int)word[2], 2);
-                        YP_WRITELANE(mhi, (int)(unsigned int)(word[2] >> 32), 2);
-                        YP_WRITELANE(mlo, (int)(unsigned int)word[3], 3);
-                        YP_WRITELANE(mhi, (int)(unsigned int)(word[3] >> 32), 3);
-                        if (lane < kImgUnit && jr + lane < n_rows)
-                            cw[jr + lane] = ((u64)(unsigned int)mhi << 32) | (u64)(unsigned int)mlo;
+                        // lanes 0..3 store the half-words of the columns jr .. jr + 3, lanes
+                        // 32..35 those of jr + 4 .. jr + 7: one store instead of eight (the words
+                        // are uniform over the wave; v_writelane puts one into one lane)
+                        int mv = 0;
+                        YP_WRITELANE(mv, (int)(unsigned int)word[0], 0);
+                        YP_WRITELANE(mv, (int)(unsigned int)(word[0] >> 32), 32);
+                        YP_WRITELANE(mv, (int)(unsigned int)word[1], 1);
+                        YP_WRITELANE(mv, (int)(unsigned int)(word[1] >> 32), 33);
+                        YP_WRITELANE(mv, (int)(unsigned int)word[2], 2);
+                        YP_WRITELANE(mv, (int)(unsigned int)(word[2] >> 32), 34);
+                        YP_WRITELANE(mv, (int)(unsigned int)word[3], 3);
+                        YP_WRITELANE(mv, (int)(unsigned int)(word[3] >> 32), 35);
+                        const int jc = jr + 4 * half + hl;
+                        if (hl < 4 && jc < n_rows) hw[jc] = (unsigned int)mv;
                     }
                 }
                 if (ties_class >= 0 && ties != 0u && lane == 0) atomicAdd(&s_tiesc[ties_class], ties);
@@ -410,13 +439,22 @@ void k_image_nms(SegArgs s)
         // -- sweep: one wave per class of the group, pure bit operations on the mask
         for (int c = g0 + wv; c < g1; c += kImgWaves) {
             const int kc = s_cnt[c];
-            const int bs = img_cand(s_pref[c << 3]);
+            const int bs = img_cand(s_pref[c << 4]);
             const int nwords = (kc + 63) >> 6;
             const size_t reg = ibase + bs;
             int nkept = 0;
             u64 keptw[kSmallWords];
 #pragma unroll
             for (int w = 0; w < kSmallWords; ++w) keptw[w] = 0ull;
+            // rows 64w .. 64w + 63 that suppress column j: the half-words of the strips 2w and 2w + 1
+            // (the second one starts at column 64w + 32)
+            auto mask_word = [&](int w, int j) {
+                const int jrel = j - (w << 6);
+                const unsigned int lo = pool32[img_words(s_pref[(c << 4) + 2 * w]) - m0 + jrel];
+                const unsigned int hi =
+                    jrel >= 32 ? pool32[img_words(s_pref[(c << 4) + 2 * w + 1]) - m0 + jrel - 32] : 0u;
+                return ((u64)hi << 32) | (u64)lo;
+            };
 #pragma unroll
             for (int cwd = 0; cwd < kSmallWords; ++cwd) {
                 if (cwd < nwords && nkept < max_out) {
@@ -424,9 +462,8 @@ void k_image_nms(SegArgs s)
                     const int jj = j < kc ? j : (cwd << 6);
                     bool alive = j < kc;
 #pragma unroll
-                    for (int w = 0; w < cwd; ++w)
-                        alive = alive && (s_pool[img_words(s_pref[(c << 3) + w]) - m0 + jj - (w << 6)] & keptw[w]) == 0ull;
-                    const u64 mycol = (j < kc) ? s_pool[img_words(s_pref[(c << 3) + cwd]) - m0 + jj - (cwd << 6)] : 0ull;
+                    for (int w = 0; w < cwd; ++w) alive = alive && (mask_word(w, jj) & keptw[w]) == 0ull;
+                    const u64 mycol = (j < kc) ? mask_word(cwd, jj) : 0ull;
                     // greedy keep set of the chunk as the fixed point of
                     // keep[i] = alive[i] && no kept earlier row of the chunk suppresses i
                     u64 keep = __ballot(alive);

@@ -117,14 +117,16 @@ def make_sets(pkg, n_sets, B, inp_dim, seed, clustered=False):
     ("graph flag set, no segment large enough", 1, 2, 96, 0.3, True, True, None),
     ("segments of ~7400: LDS-blocked sort in global memory, graph path", 1, 1, (640, 960), 0.001, False, True, None),
 ])
-def test_emulated_detect_matches_oracle(pkg, emu, name, n_sets, B, inp_dim, conf, clustered, dense, frame):
+def test_emulated_detect_matches_oracle(pkg, emu, nms_path, name, n_sets, B, inp_dim, conf, clustered, dense, frame):
     syn = pkg.synthetic
+    if nms_path == "image" and ("7400" in name or "two sets" in name or "graph flag set" in name):
+        pytest.skip("large segments behind the per-image kernel are covered by the ~1500 cases")
     sets = make_sets(pkg, n_sets, B, inp_dim, 500, clustered)
     emul_counters(emu)
     out, cnt, st = run_detect(pkg, emu, sets, inp_dim, conf, dense=dense, frame=frame, offset=3)
     c = emul_counters(emu)
-    # front, per-image NMS, per-segment NMS, row gather; the two graph kernels only with the flag
-    assert c["launches"] == (6 if dense else 4), c
+    # front, [per-image NMS,] per-segment NMS, row gather; the two graph kernels only with the flag
+    assert c["launches"] == (5 if dense else 3) + (nms_path == "image"), c
     assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c      # every collective was wave-uniform
     for k, heads in enumerate(sets):
         want, surv, _ = oracle.n_detect(heads, inp_dim, syn.YOLOV3_ANCHORS, 5, conf, 0.4)
@@ -154,7 +156,7 @@ def test_emulated_narrow_batches_of_the_pair_kernel(pkg):
         emul_counters(lib)
         out, cnt, st = run_detect(pkg, lib, sets, (320, 480), 0.01, dense=True)
         c = emul_counters(lib)
-        assert c["launches"] == 6 and c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, (name, c)
+        assert c["launches"] == 5 and c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, (name, c)
         for k, heads in enumerate(sets):
             want, surv, _ = oracle.n_detect(heads, (320, 480), syn.YOLOV3_ANCHORS, 5, 0.01, 0.4)
             assert cnt[k] == len(want) and np.array_equal(out[k, :len(want)], want), name
@@ -381,7 +383,10 @@ def test_emulated_kernels_under_address_and_ub_sanitizers(pkg, tmp_path):
         ("graph overflow rescale", 1, 1, (320, 480), 0.01, True, L.YP_FLAG_DENSE_NMS | L.YP_FLAG_RESCALE,
          (1280.0, 1920.0), 0.3),
     ]
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0")
+    # (YP_IMG_MIN_IMAGES=1: every launch goes through the per-image NMS kernel first, which finishes the
+    # small cases and hands the large ones to the per-segment kernel -- both run under the sanitizers)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0",
+               YP_IMG_MIN_IMAGES="1")
     replays = []
     for k, (name, n_sets, B, inp_dim, conf, clustered, flags, frame, cap_frac) in enumerate(cases):
         sets = make_sets(pkg, n_sets, B, inp_dim, 300, clustered)
@@ -563,7 +568,7 @@ def test_emulated_kernels_under_thread_sanitizer(pkg, tmp_path):
     shows that the detection is alive."""
     syn, L = pkg.synthetic, pkg._lib
     exe = _make("emul_driver_tsan")
-    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:exitcode=0")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:exitcode=0", YP_IMG_MIN_IMAGES="1")
     cases = [("small", 2, 2, 96, 0.3, True, 0), ("chunked", 1, 1, 416, 0.01, False, 0),
              ("graph", 1, 1, 416, 0.01, False, L.YP_FLAG_DENSE_NMS)]
     replays = []

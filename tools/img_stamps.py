@@ -35,9 +35,13 @@ eng.run(sets)
 torch.cuda.synchronize()
 L.yp_debug_set_stamps(None)
 n_img = SETS * B
-t = dbg.cpu().numpy()[:n_img].astype(np.float64) * 10.0 / 1000.0   # ticks of 10 ns -> us
+raw = dbg.cpu().numpy()[:n_img]
+ok = (raw[:, :7] > 0).all(1)
+print("workgroups with all seven stamps: %d of %d" % (ok.sum(), n_img))
+t = raw[ok].astype(np.float64) * 10.0 / 1000.0   # ticks of 10 ns -> us
 names = ["gather", "strips", "sort", "boxes", "pairs", "sweep"]
 t0 = t[:, 0].min()
+print("start times, percentiles 50/90/99: %s us" % np.round(np.percentile(t[:, 0] - t[:, 0].min(), [50, 90, 99]), 2))
 print("images %d; last start %.2f us, last end %.2f us (relative to the first start)"
       % (n_img, (t[:, 0] - t0).max(), (t[:, 6] - t0).max()))
 for k, n in enumerate(names):
