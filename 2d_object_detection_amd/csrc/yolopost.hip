@@ -2184,6 +2184,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_rows(GatherArgs g)
 // images of the set are summed once per image instead of once per segment, and the image's rows of
 // all classes are written by one flat loop, so a few hundred rows keep 256 threads busy.
 constexpr int kGatherImgClasses = 64;
+constexpr int kGatherImgMinImages = 128;
 __global__ __launch_bounds__(kGatherThreads) void k_gather_image(GatherArgs g)
 {
     __shared__ int s_part[kGatherThreads / 64];
@@ -2721,7 +2722,10 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
     g.cap = cap;
     g.out_count = out_count;
     g.stats = stats;
-    if ((stages & 4) && p->num_classes <= kGatherImgClasses)
+    // one workgroup per image once there are enough images to fill the GPU that way (an image may
+    // hold tens of thousands of rows), else one per segment
+    const int gather_min = kGatherImgMinImages < image_path_min_images() ? kGatherImgMinImages : image_path_min_images();
+    if ((stages & 4) && p->num_classes <= kGatherImgClasses && n_sets * p->batch >= gather_min)
         YP_LAUNCH(2, k_gather_image, dim3(n_sets * p->batch), dim3(kGatherThreads), 0, st, g);
     else if (stages & 4)
         YP_LAUNCH(2, k_gather_rows, dim3(n_seg), dim3(kGatherThreads), 0, st, g);
