@@ -9,6 +9,9 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-c
 if [ "$1" = "build" ]; then
   for v in $VARIANTS; do
     name=${v%%:*}; defs=$(echo "${v#*:}" | tr ',' ' ')
+    rm -f 2d_object_detection_amd/libyolopost_$name.so
+    python3 tools/kernel_resources.py --check tests/golden/kernel_resources.json $defs ||
+        { echo "  $name: leaves the resource table, NOT built"; continue; }
     /opt/rocm/bin/hipcc $FLAGS $defs -shared -o 2d_object_detection_amd/libyolopost_$name.so \
         $CSRC/yolopost.hip $CSRC/gridcodec.hip $CSRC/decode_grad.hip $CSRC/metrics.hip 2>&1 | grep -v hip-link || true
     /opt/rocm/bin/hipcc $FLAGS $defs -S --cuda-device-only -Rpass-analysis=kernel-resource-usage -o /dev/null $CSRC/yolopost.hip 2>&1 |
@@ -21,6 +24,7 @@ OUT=gpurun_out/ab_image.txt
 for v in $VARIANTS; do
   name=${v%%:*}
   export YOLOPOST_LIB=$PWD/2d_object_detection_amd/libyolopost_$name.so
+  [ -f $YOLOPOST_LIB ] || { echo "== $name: not built (refused by the resource check)" | tee -a $OUT; continue; }
   echo "== $name" | tee -a $OUT
   timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py -x -q -m gpu --timeout 200 --timeout-method thread -k "v3" \
       > gpurun_out/abi_$name.parity.log 2>&1 || { head -n 40 gpurun_out/abi_$name.parity.log; echo "$name: parity FAILED, stopping" | tee -a $OUT; exit 1; }

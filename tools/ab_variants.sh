@@ -1,8 +1,9 @@
 # A/B of compile-time variants on the GPU box: the large-segment NMS kernels (columns per batch,
 # row tile, waves per SIMD) and the XCD-aware tile order of the front kernel (-DYP_FRONT_XCD).
-# The variants in the shipped resource class (no scratch, 3 waves per SIMD) come first; the ones
-# that change the occupancy target come last, so a fault there costs nothing before it.  Build the
-# variants HERE first (on the CPU, before the gpurun call):
+# Only variants in the shipped resource class are built: tools/kernel_resources.py compares every
+# kernel of a variant with tests/golden/kernel_resources.json, and a variant that spills more,
+# takes more LDS or loses occupancy is refused here, on the CPU.  Build the variants HERE first
+# (before the gpurun call):
 #     bash tools/ab_variants.sh build
 # then on the GPU box (one call):
 #     bash tools/ab_variants.sh run
@@ -10,12 +11,15 @@
 # timed; the script stops at the first failing step, so a variant that faults never gets a second
 # launch.  Results: gpurun_out/ab_variants.txt (the HEAD of every log is kept as well).
 set -e
-VARIANTS="base: xcd:-DYP_FRONT_XCD c32:-DYP_GRAPH_COLS=32 c16:-DYP_GRAPH_COLS=16 wl:-DYP_RESOLVE_WORKLIST=1 t64w4:-DYP_GRAPH_TILE=64,-DYP_GRAPH_WPE=4 t128w4:-DYP_GRAPH_TILE=128,-DYP_GRAPH_WPE=4 c16t64w4:-DYP_GRAPH_COLS=16,-DYP_GRAPH_TILE=64,-DYP_GRAPH_WPE=4"
+VARIANTS="base: xcd:-DYP_FRONT_XCD c32:-DYP_GRAPH_COLS=32 c16:-DYP_GRAPH_COLS=16 wl:-DYP_RESOLVE_WORKLIST=1"
 CSRC=2d_object_detection_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function -Iinclude -I$CSRC"
 if [ "$1" = "build" ]; then
   for v in $VARIANTS; do
     name=${v%%:*}; defs=$(echo "${v#*:}" | tr ',' ' ')
+    rm -f 2d_object_detection_amd/libyolopost_$name.so
+    python3 tools/kernel_resources.py --check tests/golden/kernel_resources.json $defs ||
+        { echo "  $name: leaves the resource table, NOT built"; continue; }
     /opt/rocm/bin/hipcc $FLAGS $defs -shared -o 2d_object_detection_amd/libyolopost_$name.so \
         $CSRC/yolopost.hip $CSRC/gridcodec.hip $CSRC/decode_grad.hip $CSRC/metrics.hip
     /opt/rocm/bin/hipcc $FLAGS $defs -S --cuda-device-only -Rpass-analysis=kernel-resource-usage -o /dev/null $CSRC/yolopost.hip 2>&1 |
@@ -28,6 +32,7 @@ OUT=gpurun_out/ab_variants.txt
 for v in $VARIANTS; do
   name=${v%%:*}
   export YOLOPOST_LIB=$PWD/2d_object_detection_amd/libyolopost_$name.so
+  [ -f $YOLOPOST_LIB ] || { echo "== $name: not built (refused by the resource check)" | tee -a $OUT; continue; }
   echo "== $name" | tee -a $OUT
   timeout -k 10 600 python -u -m pytest tests/test_u_dense_nms.py -x -q -m gpu --timeout 200 --timeout-method thread \
       -k "rows_match or from_heads" > gpurun_out/ab_$name.parity.log 2>&1 || { head -n 40 gpurun_out/ab_$name.parity.log; echo "$name: parity FAILED, stopping" | tee -a $OUT; exit 1; }
