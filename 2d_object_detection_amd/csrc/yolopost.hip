@@ -412,25 +412,7 @@ void k_front_heads_v3_wave(HeadsArgs ha, CandBuf cb, float conf,
                                                  // padded so that a record is whole float4s
     constexpr int V = 5 + CS;
     static_assert(kFrontCells == 128, "two cells per lane");
-#ifdef YP_FRONT_XCD
-    // Experimental (off by default, to be timed): workgroups L and L + 8 share an XCD and its L2, so
-    // every XCD is dealt a contiguous run of (set, image, tile) triples.  Neighbouring tiles of a
-    // head share a cache line per channel plane wherever the plane does not start on a line
-    // boundary (every other plane of a 52 x 52 head); with both tiles on one XCD that line is
-    // fetched into one L2 once.  Any bijection of workgroups to tiles is correct.
-    int tile, bl, set;
-    {
-        const int nblk = (int)(gridDim.x * gridDim.y * gridDim.z);
-        const int lin = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
-        const int x = lin & 7, k = lin >> 3, per = nblk >> 3, rem = nblk & 7;
-        const int pos = x < rem ? x * (per + 1) + k : rem * (per + 1) + (x - rem) * per + k;
-        tile = pos % (int)gridDim.x;
-        bl = pos / (int)gridDim.x % (int)gridDim.y;
-        set = pos / (int)(gridDim.x * gridDim.y);
-    }
-#else
     const int tile = blockIdx.x, bl = blockIdx.y, set = blockIdx.z;
-#endif
     const int b = set * ha.bps + bl;     // image index inside the launch
     int h = 0;
 #pragma unroll
@@ -2676,9 +2658,7 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
         ga.seg_kept = w.seg_kept;
         ga.seg_pairs = w.seg_pairs;
         ga.seg_ties = w.seg_ties;
-#if YP_RESOLVE_WORKLIST
         ga.work = reinterpret_cast<int *>(w.sbox);
-#endif
         // pair tests: a fixed number of workgroups that share out the batches of all graph
         // segments; resolve: one workgroup per graph segment (those beyond their number leave)
         const long long slots_all = (long long)n_seg / p->num_classes * spi;

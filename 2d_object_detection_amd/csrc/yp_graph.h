@@ -45,18 +45,11 @@ constexpr int kGraphEdges = 8;            // recorded suppressors per column (th
 #ifndef YP_GRAPH_WAVEMODE
 #define YP_GRAPH_WAVEMODE 0
 #endif
-// Columns of a k_graph_pairs batch: 64 (one per lane), or 32 / 16 with every column held by
-// 2 / 4 lanes that test it against different rows at the same time.  A narrower batch covers a
-// smaller patch of the plane, so fewer rows reach it; the number of batches grows instead.
-#ifndef YP_GRAPH_COLS
-#define YP_GRAPH_COLS 64
-#endif
-static_assert(YP_GRAPH_COLS == 64 || YP_GRAPH_COLS == 32 || YP_GRAPH_COLS == 16, "columns per batch");
-// k_graph_resolve: 1 = after its first round a round only visits the columns the round before left
-// undecided (a work list) instead of all of them; most columns are decided in the first two rounds.
-#ifndef YP_RESOLVE_WORKLIST
-#define YP_RESOLVE_WORKLIST 0
-#endif
+// Columns of a k_graph_pairs batch: 32, every column held by two lanes that test it against
+// different rows at the same time.  A narrower batch covers a smaller patch of the plane, so
+// fewer rows reach it; the number of batches grows instead.  (Measured on an MI355X at 1920x1280:
+// 64 columns 4.89 ms per 32 images at 29 500 candidates per segment, 32 columns 4.49 ms, 16
+// columns 5.02 ms; 401 / 366 / 374 us at 2 000 candidates per segment.)
 constexpr int kGraphRowTile = YP_GRAPH_TILE;   // candidate rows a wave fetches per pass
 constexpr int kGraphThreads = 256;        // k_graph_pairs workgroup
 constexpr int kGraphWaves = kGraphThreads / 64;
@@ -96,10 +89,8 @@ struct GraphArgs {
     int *seg_kept;               // [n_seg]
     unsigned int *seg_pairs;     // [n_seg]
     unsigned int *seg_ties;      // [n_seg]
-#if YP_RESOLVE_WORKLIST
     int *work;                   // [4 * B*spi] two work lists per segment (the sorted-box area, which
                                  // nothing reads after the index was built)
-#endif
 };
 
 // Size of a box for the class test: the larger of the width and height terms the IoU uses.
@@ -163,7 +154,8 @@ __device__ __forceinline__ int wave_max_i(int v)
 }
 
 constexpr int kGraphBuf = kGraphRowTile + 64;   // useful rows a wave collects before testing
-constexpr int kGraphCols = YP_GRAPH_COLS;
+constexpr int kGraphCols = 32;
+static_assert(kGraphCols == 64 || kGraphCols == 32 || kGraphCols == 16, "columns per batch");
 static_assert(kGraphBuf % (4 * (64 / kGraphCols)) == 0, "padding of a flush stays inside the buffer");
 
 // Per-wave LDS of a walk.
@@ -461,9 +453,7 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
     __shared__ int s_edge[kSegWaves][64][kGraphEdges];
     __shared__ GraphSeg s_gs;
     __shared__ int s_undecided, s_redo;
-#if YP_RESOLVE_WORKLIST
     __shared__ int s_nwork;
-#endif
     __shared__ u64 s_bal[kSegWaves];
     if ((int)blockIdx.x >= ctrl[1]) return;
     const int seg = a.glist[blockIdx.x];
@@ -490,29 +480,21 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
     // another wave has just written is as good as reading it a round later.  Every round
     // decides at least the lowest-ranked undecided column (all its suppressors are decided), or
     // re-derives its list and decides it in the next: the loop ends after at most 2K rounds.
-#if YP_RESOLVE_WORKLIST
+    // After its first round a round only visits the columns the round before left undecided (a
+    // work list) instead of all of them: most columns are decided in the first two rounds.
     int *wl_a = a.work + reg * 4, *wl_b = wl_a + K;   // this round's / the next round's columns
 #define YP_WL_PUSH(p) (wl_b[atomicAdd(&s_nwork, 1)] = (p))
-#else
-#define YP_WL_PUSH(p) ((void)0)
-#endif
     int n_work = K;     // columns this round visits: all of them, or the work list's
     for (int round = 0; round < 2 * K + 2; ++round) {
         if (tid == 0) {
             s_undecided = 0;
             s_redo = 0;
-#if YP_RESOLVE_WORKLIST
             s_nwork = 0;
-#endif
         }
         __syncthreads();
         int undecided = 0, redo = 0;
         for (int q = tid; q < n_work; q += kSegThreads) {
-#if YP_RESOLVE_WORKLIST
             const int p = round > 0 ? wl_a[q] : q;
-#else
-            const int p = q;
-#endif
             const int r = xidx[p];
             if (status[r] != kUndecided) continue;
             const int cnt = gcnt[p];
@@ -547,14 +529,12 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
         if (redo) atomicAdd(&s_redo, redo);
         __syncthreads();
         if (s_undecided == 0) break;
-#if YP_RESOLVE_WORKLIST
         {   // (read before thread 0 clears the counter at the top of the loop)
             n_work = s_nwork;
             int *t = wl_a;
             wl_a = wl_b;
             wl_b = t;
         }
-#endif
         if (s_redo != 0) {
             // re-derive the suppressor lists of the flagged columns from the index, leaving out
             // rows that are suppressed by now; a kept suppressor settles the column on the spot

@@ -1,5 +1,5 @@
-# A/B of compile-time variants on the GPU box: the large-segment NMS kernels (columns per batch,
-# row tile, waves per SIMD) and the XCD-aware tile order of the front kernel (-DYP_FRONT_XCD).
+# A/B of compile-time variants of the large-segment NMS kernels on the GPU box (row tile of the
+# pair kernel, waves per SIMD).
 # Only variants in the shipped resource class are built: tools/kernel_resources.py compares every
 # kernel of a variant with tests/golden/kernel_resources.json, and a variant that spills more,
 # takes more LDS or loses occupancy is refused here, on the CPU.  Build the variants HERE first
@@ -11,7 +11,7 @@
 # timed; the script stops at the first failing step, so a variant that faults never gets a second
 # launch.  Results: gpurun_out/ab_variants.txt (the HEAD of every log is kept as well).
 set -e
-VARIANTS="base: xcd:-DYP_FRONT_XCD c32:-DYP_GRAPH_COLS=32 c16:-DYP_GRAPH_COLS=16 wl:-DYP_RESOLVE_WORKLIST=1"
+VARIANTS="base: t64w4:-DYP_GRAPH_TILE=64,-DYP_GRAPH_WPE=4 t128w4:-DYP_GRAPH_TILE=128,-DYP_GRAPH_WPE=4"
 CSRC=2d_object_detection_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function -Iinclude -I$CSRC"
 if [ "$1" = "build" ]; then
