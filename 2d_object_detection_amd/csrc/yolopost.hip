@@ -38,10 +38,7 @@ typedef unsigned long long u64;
 constexpr int kRowTile = 256;     // rows per tile in the row-mapped front kernels
 constexpr int kFrontGroups = 2;   // 64-cell groups per tile of the YOLOv3 heads front kernel
 constexpr int kFrontCells = 64 * kFrontGroups;
-#ifndef YP_STAGE_WIN
-#define YP_STAGE_WIN 128
-#endif
-constexpr int kStageWin = YP_STAGE_WIN;    // survivors staged per round by the single-wave front kernel
+constexpr int kStageWin = 128;    // survivors staged per round by the single-wave front kernel
 constexpr int kSegThreads = 512;  // threads per NMS workgroup (the kernel is only validated for 512)
 constexpr int kSegWaves = kSegThreads / 64;
 constexpr int kSortCap = 2048;    // largest segment whose keys are gathered straight into LDS
@@ -52,12 +49,8 @@ constexpr int kSmallWords = kSmallCap / 64;
 constexpr int kMaskWords = kSmallWords * kSmallCap - 32 * kSmallWords * (kSmallWords - 1);
 constexpr int kRawBytes = (kSortCap * 8 > kMaskWords * 8) ? kSortCap * 8 : kMaskWords * 8;
 constexpr int kSmallBytes = 32 * (kSmallCap + 8) + 16 * 32;   // + 32 boxes the pair loop may over-read
-#ifndef YP_GRAPH_MIN
-#define YP_GRAPH_MIN 768
-#endif
-#ifndef YP_GRAPH_WGS
-#define YP_GRAPH_WGS 1280
-#endif
+constexpr int kGraphMinCand = 768;      // segments with more candidates can take the graph path
+constexpr int kGraphPairGrid = 1280;    // workgroups of k_graph_pairs at most
 struct GraphSeg;
 
 // ------------------------------------------------------------------------ device structs
@@ -1013,14 +1006,8 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l)
 // ------------------------------------------------------------------------------ segment NMS
 // Kept rows of up to kPend chunks wait in LDS before one pass over the later columns applies
 // them all ("flush"); until then every new chunk is first tested against the waiting rows.
-#ifndef YP_PEND
-#define YP_PEND 4
-#endif
-constexpr int kPend = YP_PEND;
-#ifndef YP_PEND_LONG
-#define YP_PEND_LONG 8192
-#endif
-constexpr int kPendLongList = YP_PEND_LONG;   // segments above this use all kPend chunks of room
+constexpr int kPend = 4;
+constexpr int kPendLongList = 8192;   // segments above this use all kPend chunks of room
 
 // LDS scratch of the chunk loop.
 struct ChunkShared {
@@ -1035,10 +1022,7 @@ struct ChunkShared {
 // Greedy NMS over K sorted rows in chunks of 64.  sbox / removed / sslot are indexed by
 // sorted position and live either in LDS (small segments) or in the global workspace.
 // Returns the number of kept rows; emits each kept row through `emit(m, sorted_pos, box)`.
-#ifndef YP_COL_UNROLL
-#define YP_COL_UNROLL 4
-#endif
-constexpr int kColUnroll = YP_COL_UNROLL;
+constexpr int kColUnroll = 4;
 
 // Staged suppression test of one row per lane (pi, valid where row_ok) against U columns that
 // are uniform over the wave: words[u] has bit l set when lane l's row suppresses column u.
@@ -1351,13 +1335,6 @@ __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *rem
 #include "yp_image.h"
 
 template <int MODE>
-#ifndef YP_PAIR_UNROLL
-#define YP_PAIR_UNROLL 3
-#endif
-#ifndef YP_NMS_MIN_WAVES
-#define YP_NMS_MIN_WAVES 6
-#define YP_NMS_MAX_WAVES 6
-#endif
 __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vblk, const int nblk)
 {
     [[maybe_unused]] const int stamp_block = vblk;   // (diagnostic builds)
@@ -1588,7 +1565,7 @@ __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vbl
         // columns so that neighbouring instructions do not depend on each other.  Same
         // arithmetic and guard bands as yp_suppress_pretest (one-instruction min/max);
         // undecided lanes take the exact divide-and-compare.
-        constexpr int kPairUnroll = YP_PAIR_UNROLL;
+        constexpr int kPairUnroll = 3;
         const int wu = __builtin_amdgcn_readfirstlane(wave);
         // mask words of the columns [cbeg, cend) against the row words [0, wend)
         auto build_mask = [&](int cbeg, int cend, int wend) {
@@ -2098,7 +2075,7 @@ __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vbl
 // One workgroup per segment.
 template <int MODE>
 __global__ __launch_bounds__(kSegThreads)
-__attribute__((amdgpu_waves_per_eu(YP_NMS_MIN_WAVES, YP_NMS_MAX_WAVES)))
+__attribute__((amdgpu_waves_per_eu(6, 6)))   // 80 vector registers: three workgroups per CU
 void k_segment_nms(SegArgs s)
 {
     segment_nms_body<MODE>(s, (int)blockIdx.x, (int)gridDim.x);
@@ -2106,10 +2083,7 @@ void k_segment_nms(SegArgs s)
 
 
 // --------------------------------------------------------------------- final row gather
-#ifndef YP_GATHER_THREADS
-#define YP_GATHER_THREADS 256
-#endif
-constexpr int kGatherThreads = YP_GATHER_THREADS;
+constexpr int kGatherThreads = 256;
 __global__ __launch_bounds__(kGatherThreads) void k_gather_rows(GatherArgs g)
 {
     __shared__ int s_part[kGatherThreads / 64];
@@ -2665,7 +2639,7 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
         long long n_tables = slots_all / kGraphMin + 1;
         n_tables = n_tables < n_seg ? n_tables : n_seg;
         long long n_wg = slots_all / 64 / 2 + 1;
-        n_wg = n_wg > YP_GRAPH_WGS ? YP_GRAPH_WGS : n_wg;
+        n_wg = n_wg > kGraphPairGrid ? kGraphPairGrid : n_wg;
         YP_LAUNCH(3, k_graph_pairs<YP_MODE_YOLOV3>, dim3((unsigned)n_wg), dim3(kGraphThreads), 0, st, ga,
                   w.ctrl);
         YP_LAUNCH(4, k_graph_resolve<YP_MODE_YOLOV3>, dim3((unsigned)n_tables), dim3(kSegThreads), 0, st, ga,

@@ -32,25 +32,22 @@
 // segments that do not qualify stay on the chunked path of k_segment_nms.
 #pragma once
 
-constexpr int kGraphMin = YP_GRAPH_MIN;   // segments with more candidates take this path
+constexpr int kGraphMin = kGraphMinCand;  // segments with more candidates take this path
 constexpr int kGraphBins = 4096;          // bins of a segment's index (all classes together)
 constexpr int kGraphClasses = 8;          // size classes (powers of two of max(width, height))
 constexpr int kGraphEdges = 8;            // recorded suppressors per column (the earliest + 7)
-#ifndef YP_GRAPH_TILE
-#define YP_GRAPH_TILE 256
-#endif
-#ifndef YP_GRAPH_WPE
-#define YP_GRAPH_WPE 3
-#endif
-#ifndef YP_GRAPH_WAVEMODE
-#define YP_GRAPH_WAVEMODE 0
-#endif
 // Columns of a k_graph_pairs batch: 32, every column held by two lanes that test it against
 // different rows at the same time.  A narrower batch covers a smaller patch of the plane, so
 // fewer rows reach it; the number of batches grows instead.  (Measured on an MI355X at 1920x1280:
 // 64 columns 4.89 ms per 32 images at 29 500 candidates per segment, 32 columns 4.49 ms, 16
 // columns 5.02 ms; 401 / 366 / 374 us at 2 000 candidates per segment.)
-constexpr int kGraphRowTile = YP_GRAPH_TILE;   // candidate rows a wave fetches per pass
+// Candidate rows a wave fetches per pass, and the waves per SIMD k_graph_pairs is compiled for
+// (128 vector registers, no scratch).  Measured on an MI355X, pair kernel per 32 images at
+// 1920x1280: tiles of 256 rows at 3 waves per SIMD 4.47 ms / 368 us / 1.10 ms (29 500 candidates
+// per segment / 2 000 / clustered scenes), 128 rows at 4 waves 4.57 ms / 324 us / 0.95 ms, 64 rows
+// at 4 waves 4.80 ms / 309 us / 0.89 ms.
+constexpr int kGraphRowTile = 128;
+constexpr int kGraphPairWaves = 4;
 constexpr int kGraphThreads = 256;        // k_graph_pairs workgroup
 constexpr int kGraphWaves = kGraphThreads / 64;
 constexpr int kGraphRanges = 64;          // bin ranges a wave looks up per pass
@@ -395,14 +392,13 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
 // the batches blockIdx.x, blockIdx.x + gridDim.x, ... of each (rotated from segment to segment
 // so that short segments do not all land on the first workgroups).
 template <int MODE>
-__global__ __launch_bounds__(kGraphThreads) __attribute__((amdgpu_waves_per_eu(YP_GRAPH_WPE)))
+__global__ __launch_bounds__(kGraphThreads) __attribute__((amdgpu_waves_per_eu(kGraphPairWaves)))
 void k_graph_pairs(GraphArgs a, const int *ctrl)
 {
     __shared__ GraphWaveShared s_ws[kGraphWaves];
     __shared__ GraphSeg s_gs;
     const int n_graph = ctrl[1];                    // graph segments of this launch
     if (n_graph == 0) return;
-    const bool wave_mode = YP_GRAPH_WAVEMODE && ctrl[2] >= 2 * (int)gridDim.x;   // batches of all of them
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const YpThr thr = yp_make_thr(a.thr);
     GraphWaveShared &ws = s_ws[wave];
@@ -424,20 +420,16 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
         unsigned int pairs = 0, ties = 0;
         const int n_batches = kGraphCols == 64 ? (K + 63) >> 6 : (K + kGraphCols - 1) / kGraphCols;
         const int start = (int)((blockIdx.x + (unsigned)t * 37u) % gridDim.x);
-        // With batches to spare every wave takes a batch of its own (the window set-up is then
-        // paid once per batch); with few of them the waves of a workgroup share one batch's tiles.
-        const int per_wg = wave_mode ? kGraphWaves : 1;
-        for (int grp = start; grp * per_wg < n_batches; grp += gridDim.x) {
-            const int batch = wave_mode ? grp * kGraphWaves + wave : grp;
-            if (batch >= n_batches) continue;
+        // (the waves of a workgroup share one batch's tiles)
+        for (int batch = start; batch < n_batches; batch += gridDim.x) {
             const int p = batch * kGraphCols + (lane & (kGraphCols - 1));
             const bool live = p < K;
             const float4 cj = xraw[live ? p : K - 1];
             const int my_rank = live ? xidx[p] : -1;
             bool kept_hit;
             graph_walk<MODE, false>(s_gs, off, xraw, xidx, nullptr, a.gcnt + reg, a.gedge + reg * kGraphEdges,
-                                    cj, my_rank, p, live, thr, ws, wave_mode ? 0 : wave,
-                                    wave_mode ? 1 : kGraphWaves, nullptr, pairs, ties, kept_hit);
+                                    cj, my_rank, p, live, thr, ws, wave, kGraphWaves, nullptr, pairs, ties,
+                                    kept_hit);
         }
         if (lane == 0 && pairs) atomicAdd(&a.seg_pairs[seg], pairs);
         if (lane == 0 && ties) atomicAdd(&a.seg_ties[seg], ties);

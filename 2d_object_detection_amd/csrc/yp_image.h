@@ -31,10 +31,7 @@
 // arrays k_segment_nms writes (kept_slot, seg_kept, seg_cand, seg_region, seg_pairs, seg_ties).
 #pragma once
 
-#ifndef YP_IMG_THREADS
-#define YP_IMG_THREADS 1024
-#endif
-constexpr int kImgThreads = YP_IMG_THREADS;
+constexpr int kImgThreads = 1024;
 constexpr int kImgWaves = kImgThreads / 64;
 constexpr int kImgMaxClasses = 32;            // classes an image may have on this path
 constexpr int kImgMaxTiles = 256;             // candidate tiles per image beyond which it is not tried
@@ -148,9 +145,7 @@ __device__ __forceinline__ void img_pair2(const float4 &ri, float ai, const floa
 
 template <int MODE>
 __global__ __launch_bounds__(kImgThreads)
-#if YP_IMG_THREADS == 1024
 __attribute__((amdgpu_waves_per_eu(8, 8)))   // two workgroups per CU: at most 64 vector registers
-#endif
 void k_image_nms(SegArgs s)
 {
     __shared__ __align__(16) u64 s_pool[kImgPool];

@@ -82,9 +82,13 @@ def _dense_nms(dense_nms, confidence, rows_per_image, num_classes):
     """Whether to ask for the multi-workgroup path for large NMS segments (YP_FLAG_DENSE_NMS):
     an explicit True/False wins; None decides from the configuration -- a confidence threshold
     below 0.1 on more than 2048 anchors per class lets thousands of candidates through per
-    (image, class).  Results do not depend on it, only the time does."""
+    (image, class), and so does any threshold on images of 65 536 anchors or more (1920x1280:
+    2 000 candidates per segment at 0.5, where that path is a little ahead, and several thousand
+    in crowded scenes, where it is 15-20 % ahead; its two extra launches cost about 4 us when no
+    segment is large).  Results do not depend on it, only the time does."""
     if dense_nms is None:
-        return confidence < 0.1 and rows_per_image > 2048 * max(int(num_classes), 1)
+        per_class = rows_per_image > 2048 * max(int(num_classes), 1)
+        return (confidence < 0.1 and per_class) or (rows_per_image >= 65536 and per_class)
     return bool(dense_nms)
 
 

@@ -11,7 +11,7 @@
 # timed; the script stops at the first failing step, so a variant that faults never gets a second
 # launch.  Results: gpurun_out/ab_variants.txt (the HEAD of every log is kept as well).
 set -e
-VARIANTS="base: t64w4:-DYP_GRAPH_TILE=64,-DYP_GRAPH_WPE=4 t128w4:-DYP_GRAPH_TILE=128,-DYP_GRAPH_WPE=4"
+VARIANTS="base:"
 CSRC=2d_object_detection_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function -Iinclude -I$CSRC"
 if [ "$1" = "build" ]; then
