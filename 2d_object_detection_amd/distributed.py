@@ -101,48 +101,74 @@ class PaddedRowGather:
 
 
 class PaddedSetGather:
-    """``PaddedRowGather`` for the multi-set engine: the detection rows of up to ``n_sets``
-    batches (one launch of ``YoloV3PostMulti``) leave in ONE all_gather_into_tensor.
+    """``PaddedRowGather`` for the multi-set engine: the detection rows of ``n_sets`` batches --
+    one launch of ``YoloV3PostMulti``, or several launches whose rows are exchanged together --
+    leave in ONE all_gather_into_tensor.
 
-    ``send`` is (1 + n_sets * cap, W): row 0 is a header whose first ``n_sets`` elements carry
-    the per-set row counts (float32, exact below 2**24), then ``n_sets`` slabs of ``cap`` rows
-    (``rows`` is that (n_sets, cap, W) view: hand it to the engine as its output).  ``gather``
-    enqueues the collective behind whatever the current stream holds and returns without a host
+    ``send`` is (H + n_sets * cap, W): the first H = ceil(n_sets / W) rows are a header that
+    carries the per-set row counts (float32, exact below 2**24), then ``n_sets`` slabs of ``cap``
+    rows (``rows`` is that (n_sets, cap, W) view: hand it, or a run of its slabs, to the engine as
+    its output).  ``set_counts`` stages the counts of one launch, ``gather`` enqueues the
+    collective behind whatever the current stream holds and returns without a host
     synchronisation when the backend is nccl (RCCL); nothing is allocated per call."""
 
     def __init__(self, n_sets, cap_rows, width, device, group=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
-        if not 0 < n_sets <= width:
-            raise ValueError("the header row holds one count per set: n_sets <= width")
+        if n_sets <= 0 or width <= 0:
+            raise ValueError("n_sets and width must be positive")
         if not 0 < cap_rows < (1 << 24):
             raise ValueError("cap_rows must be in (0, 2**24)")
         self.group = group
         self.world = dist.get_world_size(group)
         self.n_sets, self.cap, self.width = int(n_sets), int(cap_rows), int(width)
-        n = 1 + self.n_sets * self.cap
+        self.header_rows = -(-self.n_sets // self.width)
+        n = self.header_rows + self.n_sets * self.cap
         self.send = torch.zeros((n, self.width), dtype=torch.float32, device=device)
         self.recv = torch.zeros((self.world * n, self.width), dtype=torch.float32, device=device)
 
     @property
     def rows(self):
-        return self.send[1:].view(self.n_sets, self.cap, self.width)
+        return self.send[self.header_rows:].view(self.n_sets, self.cap, self.width)
 
-    def gather(self, counts, n_used=None):
-        """counts: (n_sets,) numeric tensor on the buffer's device; only the first ``n_used``
-        sets (default all) were produced by the launch this gather follows."""
-        n = self.n_sets if n_used is None else int(n_used)
-        if n < self.n_sets:
-            self.send[0].zero_()
-        self.send[0, :n].copy_(counts.reshape(-1)[:n])
+    @property
+    def nbytes(self):
+        """Bytes one rank sends per collective."""
+        return self.send.numel() * 4
+
+    def set_counts(self, counts, first=0, n_used=None, n_slots=None):
+        """Stages the counts of one launch: ``counts`` (numeric tensor on the buffer's device)
+        holds one count per set of the launch, of which the first ``n_used`` (default all) were
+        produced; they go to the header slots ``first ..``, and the launch's remaining slots (it
+        owns ``n_slots``, default len(counts)) read as zero."""
+        counts = counts.reshape(-1)
+        slots = counts.numel() if n_slots is None else int(n_slots)
+        n = counts.numel() if n_used is None else int(n_used)
+        if first < 0 or first + slots > self.n_sets or n > slots:
+            raise ValueError("counts do not fit the header")
+        hdr = self.send[:self.header_rows].view(-1)
+        if n < slots:
+            hdr[first + n:first + slots].zero_()
+        hdr[first:first + n].copy_(counts[:n])
+
+    def clear_counts(self, first=0, n_slots=None):
+        """Marks the header slots ``first .. first + n_slots`` (default: to the end) as unused."""
+        last = self.n_sets if n_slots is None else first + int(n_slots)
+        self.send[:self.header_rows].view(-1)[first:last].zero_()
+
+    def gather(self, counts=None, n_used=None):
+        """Enqueues the collective.  With ``counts`` (one launch that fills the whole buffer, of
+        which the first ``n_used`` sets were produced) they are staged first."""
+        if counts is not None:
+            self.set_counts(counts, 0, n_used, self.n_sets)
         dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
 
     def unpack(self):
         """[[rows of set s of rank r for s] for r] and the (world, n_sets) true counts (rows a
         rank produced beyond ``cap`` were never sent)."""
-        r = self.recv.view(self.world, 1 + self.n_sets * self.cap, self.width)
-        counts = r[:, 0, :self.n_sets].to(torch.int64).tolist()
-        body = r[:, 1:].view(self.world, self.n_sets, self.cap, self.width)
+        r = self.recv.view(self.world, self.header_rows + self.n_sets * self.cap, self.width)
+        counts = r[:, :self.header_rows].reshape(self.world, -1)[:, :self.n_sets].to(torch.int64).tolist()
+        body = r[:, self.header_rows:].view(self.world, self.n_sets, self.cap, self.width)
         rows = [[body[k, s, :min(int(c), self.cap)] for s, c in enumerate(counts[k])]
                 for k in range(self.world)]
         return rows, [[int(c) for c in row] for row in counts]

@@ -9,11 +9,11 @@ are already resident in HBM.  At N=1 the default workload is BASELINE.json's con
 
 How the steps are issued.  Consecutive batches are independent, so S of them (default 8) go to
 the GPU together as ONE launch per stage (yp_detect_yolov3_multi), on F engines / HIP streams
-(default: 1 on one GPU, so that every kernel has the GPU to itself and its HIP-event time is
-what a profiler sees; 2 with N > 1, where the second stream hides the exchange).  K steps are
-ceil(K/S) launches.  (--sets-per-launch 4 --in-flight 2 overlaps the HBM-bound front kernel of
-one launch with the issue-bound NMS kernel of the other: about 15 % more images/s on long runs,
-with the front kernel's own duration stretched by what it shares the GPU with.)
+(default 2: the HBM-bound front kernel of one launch overlaps the issue-bound NMS kernel of
+the other, about 20 % more images/s than one launch at a time; a kernel's own duration is then
+stretched by what it shares the GPU with, so the line also carries every kernel's time with
+the GPU to itself -- `alone` -- and --in-flight 1 times the whole loop that way).  K steps are
+ceil(K/S) launches.
 
 What the steps read.  The timed loop cycles through R distinct input sets with R x bytes per
 batch >= 512 MiB (20 sets at cfg2), twice the 256 MiB Infinity Cache, so every batch is read
@@ -28,8 +28,9 @@ With N>1 (launched by torch.distributed.run, one rank per GPU) every rank proces
 batches of the same size (weak scaling).  Images are independent, so the kernels need no
 collective; the ranks exchange their variable-length detection lists with one fixed-capacity
 RCCL all-gather per launch (i.e. every batch's rows reach every rank), enqueued behind the
-launch's kernels on its stream.  `value` includes that exchange; `value_no_exchange` is the
-same loop without it.
+launch's kernels on its stream; --exchange-every E sends the rows of E launches of a stream in
+one collective instead (still every batch's rows, inside the timed region).  `value` includes
+that exchange; `value_no_exchange` is the same loop without it.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the front kernel (decode + filter + compaction): algorithmic bytes per launch
@@ -211,8 +212,10 @@ def main():
                     help="independent batches handed to the GPU as one launch per stage (1..8); "
                          "0 = 8, or 1 for batches above 64 MB")
     ap.add_argument("--in-flight", type=int, default=0,
-                    help="engines x HIP streams the launches alternate between; 0 = 1 on one GPU, "
-                         "2 with N > 1 (the same on every rank)")
+                    help="engines x HIP streams the launches alternate between; 0 = 2 (the same on "
+                         "every rank)")
+    ap.add_argument("--exchange-every", type=int, default=1,
+                    help="N > 1: launches of a stream whose rows leave in one all-gather (1..8)")
     ap.add_argument("--cycle-mib", type=int, default=CYCLE_BYTES >> 20,
                     help="distinct input bytes the timed loop cycles through")
     ap.add_argument("--no-exchange", action="store_true",
@@ -258,7 +261,8 @@ def main():
     K, W = args.steps, args.warmup
     S = args.sets_per_launch or (8 if batch_bytes <= (64 << 20) else 1)
     S = max(1, min(S, _lib.YP_MAX_SETS, K))
-    F = args.in_flight if args.in_flight > 0 else (2 if multi else 1)   # the same on every rank
+    F = args.in_flight if args.in_flight > 0 else 2   # the same on every rank
+    E = max(1, min(8, args.exchange_every))           # launches per collective (N > 1)
     # R distinct input sets, a multiple of S so that the launches see a handful of fixed groups
     R = max(S, -(-(args.cycle_mib << 20) // batch_bytes))
     # (at most 48 launch groups, which the engines' descriptor cache holds: tiny batches such as
@@ -274,16 +278,19 @@ def main():
         torch.cuda.synchronize()
 
     def make_engines(with_exchange, cap=None):
+        """Per stream: the engines its launches rotate through (E with the exchange, each writing
+        straight into its own run of slabs of the stream's gather buffer; one otherwise)."""
         engines, gathers = [], []
         for _ in range(F):
-            if with_exchange:   # the engine writes straight into the payload of its gather buffer
-                g = dsb.PaddedSetGather(S, cap, 8, dev)
+            if with_exchange:
+                g = dsb.PaddedSetGather(E * S, cap, 8, dev)
                 gathers.append(g)
-                engines.append(util.YoloV3PostMulti(S, batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
-                                                    batch_offset=rank * batch, out=g.rows))
+                engines.append([util.YoloV3PostMulti(S, batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
+                                                     batch_offset=rank * batch, out=g.rows[e * S:(e + 1) * S])
+                                for e in range(E)])
             else:
-                engines.append(util.YoloV3PostMulti(S, batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
-                                                    batch_offset=rank * batch))
+                engines.append([util.YoloV3PostMulti(S, batch, inp_dim, NUM_CLASSES, conf, nms, device=dev,
+                                                     batch_offset=rank * batch)])
         return engines, gathers
 
     def launch_plan(steps):
@@ -296,16 +303,27 @@ def main():
         return plan
 
     def run_plan(plan, engines, gathers, j0=0):
+        done = [0] * F      # launches of this plan on every stream
         for j, (first, n) in enumerate(plan, j0):
             k = j % F
+            e = done[k] % len(engines[k])
             sets = [input_sets[(first + t) % R] for t in range(n)]
-            _, count = engines[k].run(sets, streams[k])
+            _, count = engines[k][e].run(sets, streams[k])
+            done[k] += 1
             if gathers:
-                # one all-gather of the launch's rows, enqueued behind its kernels on its stream;
-                # no Work object is kept and nothing waits on the host (RCCL orders the collectives
-                # of the F streams on its own stream, in the issue order every rank shares)
+                # one all-gather of the rows of E launches, enqueued behind their kernels on their
+                # stream; no Work object is kept and nothing waits on the host (RCCL orders the
+                # collectives of the F streams on its own stream, in the issue order every rank shares)
                 with torch.cuda.stream(streams[k]):
-                    gathers[k].gather(count, n)
+                    gathers[k].set_counts(count, first=e * S, n_used=n, n_slots=S)
+                    if e == E - 1:
+                        gathers[k].gather()
+        if gathers:         # groups the plan left incomplete leave now: every row is exchanged
+            for k in range(F):
+                if done[k] % E:
+                    with torch.cuda.stream(streams[k]):
+                        gathers[k].clear_counts((done[k] % E) * S)
+                        gathers[k].gather()
         return j0 + len(plan)
 
     def timed(engines, gathers):
@@ -342,7 +360,7 @@ def main():
         # than the payload
         run_plan(launch_plan(S), engines, [])
         torch.cuda.synchronize()
-        cmax = engines[0].count.to(torch.int64).max().reshape(1).clone()
+        cmax = engines[0][0].count.to(torch.int64).max().reshape(1).clone()
         dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
         cap = max(1024, -(-(int(cmax.item()) * 17 // 16) // 1024) * 1024)
         times_nx, _ = timed(engines, [])
@@ -350,11 +368,15 @@ def main():
         times, t_enq = timed(engines_x, gathers)
         torch.cuda.synchronize()
         _, counts = gathers[(len(launch_plan(W)) + repeats * len(launch_plan(K)) - 1) % F].unpack()
-        xinfo = {"exchange": "one fixed-capacity RCCL all-gather of every rank's detection rows per launch "
-                             "(%d batches), enqueued behind the launch's kernels on its stream" % S,
+        n_launch = len(launch_plan(K))
+        xinfo = {"exchange": "one fixed-capacity RCCL all-gather of every rank's detection rows per %d "
+                             "launch(es) of a stream (%d batches each), enqueued behind the kernels on "
+                             "that stream; every batch's rows are exchanged inside the timed region" % (E, S),
+                 "exchange_every": E,
                  "gather_rows_capacity_per_set": cap,
-                 "gather_bytes_per_rank_per_launch": (1 + S * cap) * 32,
-                 "gather_rows_last_launch": counts,
+                 "gather_bytes_per_rank_per_collective": gathers[0].nbytes,
+                 "collectives_per_timed_region": sum(-(-len(range(k, n_launch, F)) // E) for k in range(F)),
+                 "gather_rows_last_collective": counts,
                  "gather_overflow": bool(max(max(c) for c in counts) > cap)}
         del engines_x
     else:
@@ -375,33 +397,56 @@ def main():
     torch.cuda.synchronize()
     # (b) one launch at a time on one stream, still cycling through HBM
     alone = {}
+    eng0 = engines[0][0]
     for i in range(16):
-        engines[0].run([input_sets[(i * S + t) % R] for t in range(S)])
+        eng0.run([input_sets[(i * S + t) % R] for t in range(S)])
     torch.cuda.synchronize()
     _lib.profile_start(nprof)
     for i in range(nprof):
-        engines[0].run([input_sets[(i * S + t) % R] for t in range(S)])
+        eng0.run([input_sets[(i * S + t) % R] for t in range(S)])
     alone["front"], alone["segment_nms"], alone["gather"], _ = _lib.profile_stop()
     torch.cuda.synchronize()
     # (c) the same input sets every launch, at most 4 distinct ones (109 MB at cfg2): they stay
     # in the Infinity Cache
     cached_sets = [input_sets[t % min(S, 4)] for t in range(S)]
     for i in range(8):
-        engines[0].run(cached_sets)
+        eng0.run(cached_sets)
     _lib.profile_start(nprof)
     for i in range(nprof):
-        engines[0].run(cached_sets)
+        eng0.run(cached_sets)
     front_cached_ms, _, _, _ = _lib.profile_stop()
     torch.cuda.synchronize()
 
-    surv, kept, pairs, ties = engines[0].segment_stats()
+    surv, kept, pairs, ties = eng0.segment_stats()
     surv, kept, pairs, ties = surv[0], kept[0], pairs[0], ties[0]       # set 0 = one batch
     total_surv, total_kept = int(surv.sum()), int(kept.sum())
-    pairs_launch = float(engines[0].stats[:, 2].to(torch.int64).sum().item())
+    pairs_launch = float(eng0.stats[:, 2].to(torch.int64).sum().item())
+
+    def call_latency(n_images):
+        """One call of the drop-in engine on n_images images with nothing else on the GPU:
+        enqueue, then wait for the stream (microseconds: median and minimum of 200 calls)."""
+        eng = util.YoloV3Post(n_images, inp_dim, NUM_CLASSES, conf, nms, device=dev)
+        heads = [h[:n_images].contiguous() for h in base]
+        for _ in range(20):
+            eng.run(heads)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(200):
+            t0 = time.perf_counter()
+            eng.run(heads)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return {"images": n_images, "median": round(statistics.median(ts) * 1e6, 1), "min": round(min(ts) * 1e6, 1)}
+
+    latency = None
+    if world == 1 and not multi:
+        latency = {"one_batch": call_latency(batch), "one_image": call_latency(1),
+                   "note": "host time of one YoloV3Post.run (three kernel launches) plus the wait for its "
+                           "stream, inputs cache-resident, GPU otherwise idle"}
 
     if rank == 0:
         n_anchors = batch * rows_per_image
-        tiles = batch * sum(-(-(gh * gw) // 128) for gh, gw in engines[0].grids)
+        tiles = batch * sum(-(-(gh * gw) // 128) for gh, gw in eng0.grids)
         # algorithmic bytes of the front kernel per batch: every anchor's 10 f32 logits read
         # once, 28 B written per survivor (box 16, objectness 4, class score 4, class id 4) and
         # one int32 survivor count per 128-cell tile; a launch processes S batches
@@ -409,7 +454,7 @@ def main():
         alg_bytes = S * alg_batch
         achieved = alg_bytes / (front_ms * 1e-3) / 1e9
         traffic, traffic_note = None, None
-        tfile = os.path.join(ROOT, "profiles", "r02_front_kernel_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r03_front_kernel_traffic.json")
         if os.path.exists(tfile) and not args.clustered:
             # HBM bytes from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this benchmark,
             # collected offline and committed (see the file for the correction).  The sets of a
@@ -494,6 +539,8 @@ def main():
                                "note": "achieved = pairs the kernels evaluated / their HIP-event time "
                                        "(the kernels also gather, sort and sweep); algorithmic pairs = "
                                        "sum over segments of K(K-1)/2, what an unpruned greedy NMS tests"}
+        if latency is not None:
+            out["latency_us"] = latency
         if times_nx is not None:
             mnx = statistics.median(times_nx)
             out["value_no_exchange"] = round(world * batch * K / mnx, 1)

@@ -82,6 +82,28 @@ def _worker(rank, world, port, q):
         sg.gather(torch.tensor([3, 3, 3], dtype=torch.int64), n_used=2)
         _, c9 = sg.unpack()
         ok = ok and c9 == [[3, 3, 0]] * world
+        # the rows of several launches exchanged together: 3 launches of 4 sets in one buffer of 12
+        # (two header rows), counts staged launch by launch, the last launch partly used
+        mg = d.PaddedSetGather(12, 3, 8, torch.device("cpu"))
+        ok = ok and mg.header_rows == 2 and tuple(mg.rows.shape) == (12, 3, 8) and mg.nbytes == (2 + 36) * 32
+        for s_ in range(12):
+            mg.rows[s_, :, 0] = float(1000 * rank + s_)
+        for e in range(3):
+            launch_counts = torch.tensor([e + 1, rank, 2, 3], dtype=torch.int32)
+            mg.set_counts(launch_counts, first=4 * e, n_used=4 if e < 2 else 1)
+        mg.gather()
+        got10, c10 = mg.unpack()
+        for r in range(world):
+            want_c = [1, r, 2, 3, 2, r, 2, 3, 3, 0, 0, 0]
+            ok = ok and c10[r] == want_c
+            for s_, c in enumerate(want_c):
+                ok = ok and got10[r][s_].shape == (min(c, 3), 8)
+                ok = ok and bool((got10[r][s_][:, 0] == float(1000 * r + s_)).all())
+        # a group that ends early: the launches that did not happen read as empty
+        mg.set_counts(torch.tensor([2, 2, 2, 2], dtype=torch.int32), first=0)
+        mg.clear_counts(4)
+        mg.gather()
+        ok = ok and mg.unpack()[1] == [[2, 2, 2, 2] + [0] * 8] * world
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -503,6 +503,8 @@ def _check_v3_properties(pkg, dev, got, nms, C):
     ("cfg2-clustered", 64, 416, 0.5, 0.4, 1, True),
     ("cfg3", 32, (1280, 1920), 0.5, 0.4, 2, False),      # Waymo front camera, batch 32
     ("cfg4-shard", 64, 608, 0.5, 0.4, 3, False),         # one GPU's share of batch 512 at 608
+    ("cfg4-shard of 4 GPUs", 128, 608, 0.5, 0.4, 3, False),
+    ("cfg4-shard of 2 GPUs", 256, 608, 0.5, 0.4, 3, False),
     ("cfg5-slice", 2, (1280, 1920), 0.001, 0.4, 4, False),  # worst-case dense NMS, 2 images
 ])
 def test_v3_full_size_configs_match_oracle(pkg, dev, name, B, inp_dim, conf, nms, seed, clustered):

@@ -42,3 +42,9 @@ def test_bench_line_has_the_contract_fields():
     assert t["repeats"] == 5 and t["ms_per_step_min"] <= d["ms_per_step"] <= t["ms_per_step_max"]
     assert d["config"]["input_sets_cycled"] * d["config"]["bytes_per_batch"] >= 512 << 20
     assert r["batches_per_launch"] == d["config"]["batches_per_launch"]
+    # latency of one call beside the throughput: one batch and one image, microseconds
+    lat = d["latency_us"]
+    assert lat["one_batch"]["images"] == 64 and lat["one_image"]["images"] == 1
+    assert 0 < lat["one_image"]["min"] <= lat["one_image"]["median"] < 1e4
+    assert lat["one_image"]["median"] <= lat["one_batch"]["median"] * 1.5
+    assert d["config"]["launches_in_flight"] == 2 and d["roofline"]["kernel_ms_alone"] > 0
