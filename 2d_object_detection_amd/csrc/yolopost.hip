@@ -2799,7 +2799,6 @@ static int detect_v3_sets(const YpHead *heads, int n_heads, int n_sets, const Yp
         return YP_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(d_out_rows) & 15) != 0) return YP_ERR_ARG;
     if (n_sets < 1 || n_sets > YP_MAX_SETS) return YP_ERR_UNSUPPORTED;
-    if (n_sets > 1 && (out_cap & 1)) return YP_ERR_ARG;   // keeps every set's rows 16-byte aligned
     HeadsArgs ha;
     int amax = 0;
     const int rc = heads_geometry(heads, n_heads, params->num_classes, kFrontCells, &ha, &amax, n_sets);
@@ -2935,12 +2934,22 @@ size_t yp_rows_workspace_bytes(int batch, int rows_per_image, int segments_per_i
                  (size_t)batch * segments_per_image, nullptr);
 }
 
+// Workspace of the reference-mode entries: the arrays of yp_rows_workspace_bytes(batch, rows, 1)
+// without those of the graph path, which only YP_MODE_YOLOV3 uses.
+static size_t ref_workspace_bytes(int batch, int rows_per_image)
+{
+    if (batch <= 0 || rows_per_image <= 0) return 0;
+    const long long tpi = ((long long)rows_per_image + kRowTile - 1) / kRowTile;
+    if (!slots_fit(batch, tpi * kRowTile)) return 0;
+    return carve(nullptr, (size_t)batch * tpi * kRowTile, (size_t)batch * tpi, (size_t)batch, nullptr, false);
+}
+
 size_t yp_detect_reference_workspace_bytes(int batch, int grid_h, int grid_w, int num_anchors)
 {
     if (grid_h <= 0 || grid_w <= 0 || num_anchors <= 0) return 0;
     const long long n = (long long)grid_h * grid_w * num_anchors;
     if (n >= (1ll << 28)) return 0;
-    return yp_rows_workspace_bytes(batch, (int)n, 1);
+    return ref_workspace_bytes(batch, (int)n);
 }
 
 int yp_write_results(const float *d_rows, int rows_per_image, const YpParams *params,
@@ -2998,11 +3007,11 @@ int yp_detect_reference(const YpHead *head, const YpParams *params, float *d_out
     const int tpi = (int)((n + kRowTile - 1) / kRowTile);
     const long long spi = (long long)tpi * kRowTile;
     if (!slots_fit(params->batch, spi)) return YP_ERR_UNSUPPORTED;
-    const size_t need = yp_rows_workspace_bytes(params->batch, (int)n, 1);
+    const size_t need = ref_workspace_bytes(params->batch, (int)n);
     if (!workspace_ok(d_workspace, workspace_bytes, need)) return YP_ERR_WORKSPACE;
     Workspace w;
     carve(d_workspace, (size_t)params->batch * spi, (size_t)params->batch * tpi,
-          (size_t)params->batch, &w);
+          (size_t)params->batch, &w, false);
     CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile, w.ctrl};
     AnchorTable at = {};
     for (int i = 0; i < 2 * head->num_anchors; ++i) at.anc[i] = head->anchors[i];
@@ -3040,11 +3049,11 @@ int yp_filter_boxes_reference(const float *d_center, const float *d_wh, const fl
     const int tpi = (rows_per_image + kRowTile - 1) / kRowTile;
     const long long spi = (long long)tpi * kRowTile;
     if (!slots_fit(params->batch, spi)) return YP_ERR_UNSUPPORTED;
-    const size_t need = yp_rows_workspace_bytes(params->batch, rows_per_image, 1);
+    const size_t need = ref_workspace_bytes(params->batch, rows_per_image);
     if (!workspace_ok(d_workspace, workspace_bytes, need)) return YP_ERR_WORKSPACE;
     Workspace w;
     carve(d_workspace, (size_t)params->batch * spi, (size_t)params->batch * tpi,
-          (size_t)params->batch, &w);
+          (size_t)params->batch, &w, false);
     CandBuf cb = {w.cand_box, w.cand_key, w.cand_aux, w.cand_cls, w.tile_count, tpi, kRowTile, w.ctrl};
     hipStream_t st = (hipStream_t)stream;
     YP_LAUNCH(0, k_front_split_ref, dim3(tpi, params->batch), dim3(kRowTile), 0, st, d_center, d_wh,

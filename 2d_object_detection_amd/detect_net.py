@@ -209,7 +209,7 @@ class DetectNet():
         p = _ref_params(B)
         L = _lib.load()
         outs = _alloc_outputs(B, dev)
-        ws = _lib.workspace(L.yp_rows_workspace_bytes(B, N, 1), dev)
+        ws = _lib.workspace(L.yp_detect_reference_workspace_bytes(B, N, 1, 1), dev)
         with _lib.on_device(dev):
             rc = L.yp_filter_boxes_reference(
                 center.data_ptr(), wh.data_ptr(), obj.data_ptr(), cls.data_ptr(), N,

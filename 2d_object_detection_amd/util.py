@@ -183,7 +183,7 @@ class YoloV3Post:
 
     def __init__(self, batch, inp_dim, num_classes=5, confidence=0.5, nms_conf=0.4,
                  anchors=YOLOV3_ANCHORS, strides=(32, 16, 8), device=None, out_cap=None,
-                 batch_offset=0, out=None, dense_nms=None, frame=None):
+                 batch_offset=0, out=None, dense_nms=None, frame=None, _allocate=True):
         self.device = torch.device(device if device is not None
                                    else "cuda:%d" % torch.cuda.current_device())
         if self.device.type != "cuda":
@@ -207,6 +207,9 @@ class YoloV3Post:
                                                             self.batch, self.num_classes)
         if nbytes == 0:
             raise _lib.YoloPostError("unsupported head geometry")
+        self._desc_cache = {}
+        if not _allocate:     # geometry, parameters and head validation only (YoloV3PostMulti)
+            return
         self.workspace = _lib.workspace(nbytes, self.device)
         if out is not None:
             # caller-provided output rows (e.g. the payload view of a gather buffer)
@@ -222,7 +225,6 @@ class YoloV3Post:
         self.stats = torch.zeros((_lib.YP_STATS_PLANES, self.batch, self.num_classes),
                                  dtype=torch.int32, device=self.device)
         # everything the per-batch call needs, resolved once
-        self._desc_cache = {}
         self._detect = self._lib.yp_detect_yolov3
         self._params_ref = ctypes.byref(self.params)
         self._out_ptr, self._count_ptr = self.out.data_ptr(), self.count.data_ptr()
@@ -297,11 +299,11 @@ class YoloV3PostMulti:
         if not 1 <= int(n_sets) <= _lib.YP_MAX_SETS:
             raise ValueError("1..%d sets per call" % _lib.YP_MAX_SETS)
         self.n_sets = int(n_sets)
-        # geometry, validation and parameters are those of a single-set engine; its own
-        # buffers are sized for one image and unused
+        # geometry, validation and parameters are those of a single-set engine (which allocates
+        # no device memory of its own here)
         self._one = YoloV3Post(batch, inp_dim, num_classes, confidence, nms_conf, anchors, strides,
-                               device, out_cap=2, batch_offset=batch_offset, dense_nms=dense_nms,
-                               frame=frame)
+                               device, batch_offset=batch_offset, dense_nms=dense_nms, frame=frame,
+                               _allocate=False)
         o = self._one
         self.device, self.batch, self.num_classes = o.device, o.batch, o.num_classes
         self.grids, self.rows_per_image, self.params = o.grids, o.rows_per_image, o.params
@@ -320,15 +322,13 @@ class YoloV3PostMulti:
             # caller-provided output rows (e.g. the payload view of a gather buffer)
             _lib.require_device(out, "out")
             if (out.dtype != torch.float32 or out.dim() != 3 or out.shape[0] != self.n_sets
-                    or out.shape[2] != 8 or not out.is_contiguous() or out.data_ptr() % 16
-                    or (out.shape[1] & 1 and self.n_sets > 1)):
+                    or out.shape[2] != 8 or not out.is_contiguous() or out.data_ptr() % 16):
                 raise ValueError("out must be a contiguous 16-byte aligned float32 "
-                                 "(n_sets, even cap, 8) tensor")
+                                 "(n_sets, cap, 8) tensor")
             self.cap, self.out = out.shape[1], out
         else:
-            cap = self.batch * self.rows_per_image if out_cap is None else int(out_cap)
-            self.cap = cap + (cap & 1)     # even: every set's rows start 16-byte aligned
-            self.out = torch.empty((self.n_sets, max(self.cap, 2), 8), dtype=torch.float32,
+            self.cap = self.batch * self.rows_per_image if out_cap is None else int(out_cap)
+            self.out = torch.empty((self.n_sets, max(self.cap, 1), 8), dtype=torch.float32,
                                    device=self.device)
         self.count = torch.zeros((self.n_sets,), dtype=torch.int32, device=self.device)
         self.stats = torch.zeros((self.n_sets, _lib.YP_STATS_PLANES, self.batch, self.num_classes),
@@ -363,6 +363,9 @@ class YoloV3PostMulti:
                 self.workspace.numel(), stream)
         if rc != 0:
             _lib.check(rc, "yp_detect_yolov3_multi")
+        if n < self.n_sets:      # the sets this call did not use read as empty, not as the last call's
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                self.count[n:].zero_()
         return self.out, self.count
 
     def detect(self, sets):

@@ -157,9 +157,9 @@ int yp_detect_yolov3(const YpHead *heads, int n_heads, const YpParams *params,
  *   heads       n_sets * n_heads descriptors, set-major; every set repeats the geometry and
  *               anchors of set 0, only `data` differs
  *   params      shared by all sets; params->batch = images per set
- *   d_out_rows  (n_sets, out_cap, 8): set s writes its rows from d_out_rows + s*out_cap*8
- *               (out_cap even when n_sets > 1), image index in column 0 counts from
- *               params->batch_offset inside every set
+ *   d_out_rows  (n_sets, out_cap, 8): set s writes its rows from d_out_rows + s*out_cap*8 (a
+ *               row is 32 bytes, so every slab is 16-byte aligned when d_out_rows is); the image
+ *               index in column 0 counts from params->batch_offset inside every set
  *   d_out_count [n_sets]
  *   d_stats     optional (n_sets, 4, B, C), planes as in yp_detect_yolov3
  *   workspace   yp_detect_yolov3_workspace_bytes(heads, n_heads, n_sets * batch, C)
@@ -204,7 +204,9 @@ int yp_detect_reference(const YpHead *head, const YpParams *params, float *d_out
 
 /* ---- filter + NMS on already decoded tensors ----------------------------------------- */
 
-/* segments_per_image: num_classes for yp_write_results, 1 for the reference-mode entries. */
+/* segments_per_image: num_classes for yp_write_results.  (With 1 it is an upper bound of what the
+ * reference-mode entries need -- yp_detect_reference_workspace_bytes(batch, rows, 1, 1) is their
+ * exact size, which leaves out the arrays only YP_MODE_YOLOV3 uses.) */
 size_t yp_rows_workspace_bytes(int batch, int rows_per_image, int segments_per_image);
 
 /* YOLOv3 write_results on decoded rows (B, N, 5+C) (not in the reference; mode note

@@ -124,3 +124,62 @@ def test_cfg5_full_batch_properties(pkg, dev):
             iou[torch.arange(a.shape[0]), torch.arange(lo, lo + a.shape[0])] = 0.0      # a box with itself
             worst = max(worst, float(iou.max()))
         assert worst <= thr, (b, c, worst)
+
+
+def _write_results_abi(pkg, dev, rows, C, conf, nms, dense, max_out=0):
+    """yp_write_results through the C ABI with an output cap per segment (YpParams.max_out)."""
+    import ctypes
+    L, util = pkg._lib, pkg.util
+    lib = L.load()
+    B, N, _ = rows.shape
+    d_rows = torch.from_numpy(rows).to(dev)
+    p = util._v3_params(B, C, conf, nms, dense=dense)
+    p.max_out = max_out
+    ws = L.workspace(lib.yp_rows_workspace_bytes(B, N, C), dev)
+    out = torch.full((B * N, 8), -1.0, dtype=torch.float32, device=dev)
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    stats = torch.zeros((4, B, C), dtype=torch.int32, device=dev)
+    rc = lib.yp_write_results(d_rows.data_ptr(), N, ctypes.byref(p), out.data_ptr(), B * N, count.data_ptr(),
+                              stats.data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr(dev))
+    assert rc == 0, lib.yp_strerror(rc)
+    torch.cuda.synchronize()
+    return out[:int(count.item())].cpu().numpy(), stats.cpu().numpy()
+
+
+def test_dense_nms_on_a_score_monotone_chain(pkg, dev):
+    """A run of boxes, each overlapping only its neighbours above the threshold, with scores
+    falling along the run: box 0 is kept, suppresses box 1, box 2 is kept because its only
+    suppressor is gone, and so on -- the keep set of every box hangs on the one before it, the
+    longest dependency chain a segment of that size can have for the resolve kernel's rounds."""
+    import time
+    n, C = 1500, 2
+    rows = np.zeros((1, n, 5 + C), np.float32)
+    rows[0, :, 0] = 50.0 + 30.0 * np.arange(n)          # centres 30 px apart, boxes 100 px wide:
+    rows[0, :, 1] = 40.0                                # IoU 0.54 with the neighbour, 0.25 with the next
+    rows[0, :, 2], rows[0, :, 3] = 100.0, 60.0
+    rows[0, :, 4] = np.linspace(0.999, 0.501, n).astype(np.float32)
+    rows[0, :, 5] = 0.9
+    want, surv, _ = oracle.n_write_results(rows, 0.5, C, 0.4)
+    assert surv.max() == n and want.shape[0] == n // 2
+    for dense in (True, False):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got, _ = _write_results_abi(pkg, dev, rows, C, 0.5, 0.4, dense)
+        el = time.perf_counter() - t0
+        assert np.array_equal(got, want), dense
+        assert el < 2.0, (dense, el)                    # (hundreds of rounds, each a few microseconds)
+
+
+def test_dense_nms_with_an_output_cap_per_segment(pkg, dev):
+    """YpParams.max_out > 0 on the graph path: every (image, class) segment ends after its first
+    max_out kept rows, exactly as on the default path."""
+    rows, C = big_segment_rows(2500, 11)
+    full, _ = _write_results_abi(pkg, dev, rows, C, 0.5, 0.4, dense=False)
+    for cap in (1, 7, 300):
+        got_d, st_d = _write_results_abi(pkg, dev, rows, C, 0.5, 0.4, dense=True, max_out=cap)
+        got_o, st_o = _write_results_abi(pkg, dev, rows, C, 0.5, 0.4, dense=False, max_out=cap)
+        assert np.array_equal(got_d, got_o), cap
+        # ... which is the head of every segment of the uncapped result
+        want = np.concatenate([full[full[:, 7] == c][:cap] for c in range(C)])
+        assert np.array_equal(got_d, want), cap
+        assert np.array_equal(st_d[1], st_o[1]) and st_d[1].max() <= cap
