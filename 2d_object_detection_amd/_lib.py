@@ -28,6 +28,7 @@ YP_MATCH_NONE, YP_MATCH_DUPLICATE, YP_MATCH_OTHER_CLASS = -1, -2, -3
 EXPORTED_SYMBOLS = (
     "yp_version", "yp_strerror",
     "yp_predict_transform_reference", "yp_predict_transform_yolov3",
+    "yp_dense_relu_predict_transform_reference",
     "yp_detect_yolov3_workspace_bytes", "yp_detect_yolov3", "yp_detect_yolov3_multi",
     "yp_noalloc_scratch_bytes", "yp_noalloc_prepare", "yp_detect_yolov3_noalloc",
     "yp_detect_reference_workspace_bytes", "yp_detect_reference",
@@ -94,6 +95,9 @@ def load():
     L.yp_strerror.argtypes = [i32]
     L.yp_predict_transform_reference.restype = i32
     L.yp_predict_transform_reference.argtypes = [vp, i32, i32, i32, i32, i32, fp, vp, vp, vp, vp, vp]
+    L.yp_dense_relu_predict_transform_reference.restype = i32
+    L.yp_dense_relu_predict_transform_reference.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, fp,
+                                                            vp, vp, vp, vp, vp, vp]
     L.yp_predict_transform_yolov3.restype = i32
     L.yp_predict_transform_yolov3.argtypes = [ctypes.POINTER(YpHead), i32, i32, i32, vp, vp]
     L.yp_detect_yolov3_workspace_bytes.restype = sz

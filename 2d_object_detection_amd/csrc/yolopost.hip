@@ -2238,8 +2238,11 @@ __global__ void k_decode_heads_v3(HeadsArgs ha, float *out_rows)
     for (int i = threadIdx.x; i < nflt; i += blockDim.x) dst[i] = s_tile[i];
 }
 
+#include "yp_epilogue.h"
+
 // Reference predict_transform (detect_net.py:152-183): thread <-> row.  The raw rows come in,
-// and the class probabilities go out, through the tile staging of yp_tile.h.
+// and the class probabilities go out, through the tile staging of yp_tile.h; a record is
+// evaluated by yp_decode_record_ref (yp_epilogue.h).
 template <bool STAGED, int CS>   // CS as in k_front_grid_ref
 __global__ void k_decode_grid_ref(const float *pred, int H, int W, int A, int C_arg, AnchorTable at,
                                   float *center, float *wh, float *obj, float *cls, long long total)
@@ -2253,36 +2256,18 @@ __global__ void k_decode_grid_ref(const float *pred, int H, int W, int A, int C_
     float probs[STAGED ? kTileMaxWidth : 1];
     if (o < total) {
         const int n = (int)(o % N);
-        const int a = n % A, k = n / A;
-        const float gx = (float)(k % H), gy = (float)(k / H);
         const float *t = STAGED ? s_tile + threadIdx.x * V : pred + o * V;
         float2 ce, sz;
-        ce.x = (yp_sigmoid(t[0]) + gx) / (float)H;
-        ce.y = (yp_sigmoid(t[1]) + gy) / (float)W;
-        sz.x = (yp_exp(t[2]) * at.anc[2 * a + 0]) / (float)H;
-        sz.y = (yp_exp(t[3]) * at.anc[2 * a + 1]) / (float)W;
+        float ob;
+        if (STAGED) {
+            yp_decode_record_ref<CS>(t, n, H, W, A, C, at, ce, sz, ob, probs);
+        } else {
+            // records too wide for the staging buffer: the probabilities go straight to memory
+            yp_decode_record_ref<0>(t, n, H, W, A, C, at, ce, sz, ob, cls + o * C);
+        }
         reinterpret_cast<float2 *>(center)[o] = ce;
         reinterpret_cast<float2 *>(wh)[o] = sz;
-        obj[o] = yp_sigmoid(t[4]);
-        float m = t[5];
-        for (int j = 1; j < C; ++j) m = t[5 + j] > m ? t[5 + j] : m;
-        float s = 0.f;
-        if (CS) {   // (always staged)
-#pragma unroll
-            for (int j = 0; j < CS; ++j) probs[j] = yp_exp(t[5 + j] - m);
-#pragma unroll
-            for (int j = 0; j < CS; ++j) s = s + probs[j];
-#pragma unroll
-            for (int j = 0; j < CS; ++j) probs[j] = probs[j] / s;
-        } else if (STAGED) {
-            for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
-#pragma unroll
-            for (int j = 0; j < kTileMaxWidth; ++j)
-                if (j < C) probs[j] = yp_exp(t[5 + j] - m) / s;
-        } else {
-            for (int j = 0; j < C; ++j) s = s + yp_exp(t[5 + j] - m);
-            for (int j = 0; j < C; ++j) cls[o * C + j] = yp_exp(t[5 + j] - m) / s;
-        }
+        obj[o] = ob;
     }
     if (STAGED) {
         __syncthreads();   // every thread has read its raw row: the buffer now takes the results
@@ -2751,6 +2736,27 @@ int yp_predict_transform_reference(const float *d_pred, int batch, int grid_h, i
         hipLaunchKernelGGL((k_decode_grid_ref<false, 0>), dim3(blocks), dim3(kTileRows), 0,
                            (hipStream_t)stream, d_pred, grid_h, grid_w, num_anchors, num_classes, at,
                            d_center, d_wh, d_obj, d_cls, total);
+    return (int)hipGetLastError();
+}
+
+int yp_dense_relu_predict_transform_reference(const float *d_features, const float *d_weight,
+                                              const float *d_bias, int batch, int features, int grid_h,
+                                              int grid_w, int num_anchors, int num_classes,
+                                              const float *anchors, float *d_raw, float *d_center,
+                                              float *d_wh, float *d_obj, float *d_cls, void *stream)
+{
+    if (!d_features || !d_weight || !d_bias || !anchors || !d_center || !d_wh || !d_obj || !d_cls)
+        return YP_ERR_ARG;
+    if (batch <= 0 || features <= 0 || grid_h <= 0 || grid_w <= 0) return YP_ERR_ARG;
+    if (num_anchors < 1 || num_anchors > YP_MAX_ANCHORS) return YP_ERR_UNSUPPORTED;
+    if (num_classes != 5) return YP_ERR_UNSUPPORTED;   // (the reference's class count, params.py:31)
+    AnchorTable at = {};
+    for (int i = 0; i < 2 * num_anchors; ++i) at.anc[i] = anchors[i];
+    const long long total = (long long)batch * grid_h * grid_w * num_anchors;
+    if (total >= (1ll << 31)) return YP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((k_dense_relu_decode_ref<5>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_features, d_weight, d_bias, features, grid_h, grid_w,
+                       num_anchors, at, d_raw, d_center, d_wh, d_obj, d_cls, total);
     return (int)hipGetLastError();
 }
 

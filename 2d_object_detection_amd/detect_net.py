@@ -184,6 +184,41 @@ class DetectNet():
         return _decode_forward(pred, H, W, A, C)
 
     @staticmethod
+    def dense_relu_predict_transform(features, weight, bias, return_head=False):
+        """The head's last layer and the decode in ONE kernel: relu(features @ weight + bias)
+        (detect_net.py:67-68) decoded as predict_transform does (detect_net.py:152-183) from the
+        registers it was accumulated in, without storing the raw head.  ``features`` (B, F),
+        ``weight`` (F, H*W*A*(5+C)), ``bias`` (H*W*A*(5+C)); params.num_classes must be 5.  The
+        four outputs equal predict_transform of the stored head bit for bit (``return_head``
+        adds that head as a fifth result).  The dot products are plain loops: this shows the
+        epilogue hook a producer kernel can call, it is not a tuned dense layer."""
+        H, W = int(params.grid_height), int(params.grid_width)
+        A, C = int(params.num_anchors), int(params.num_classes)
+        x = _device_tensor(features, "features")
+        dev = x.device
+        w = _device_tensor(weight, "weight").to(dev)
+        bvec = _device_tensor(bias, "bias").to(dev)
+        n_out = H * W * A * (5 + C)
+        if x.dim() != 2 or w.dim() != 2 or w.shape != (x.shape[1], n_out) or bvec.numel() != n_out:
+            raise ValueError("features (B, F), weight (F, %d), bias (%d) expected" % (n_out, n_out))
+        B, F = x.shape
+        center = torch.empty((B, H, W, A, 2), dtype=torch.float32, device=dev)
+        wh = torch.empty((B, H, W, A, 2), dtype=torch.float32, device=dev)
+        obj = torch.empty((B, H, W, A, 1), dtype=torch.float32, device=dev)
+        cls = torch.empty((B, H, W, A, C), dtype=torch.float32, device=dev)
+        head = torch.empty((B, n_out), dtype=torch.float32, device=dev) if return_head else None
+        if B > 0:
+            anc = _anchor_array(A)
+            with _lib.on_device(dev):
+                rc = _lib.load().yp_dense_relu_predict_transform_reference(
+                    x.data_ptr(), w.data_ptr(), bvec.data_ptr(), B, F, H, W, A, C,
+                    anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                    head.data_ptr() if return_head else None,
+                    center.data_ptr(), wh.data_ptr(), obj.data_ptr(), cls.data_ptr(), _lib.stream_ptr(dev))
+            _lib.check(rc, "yp_dense_relu_predict_transform_reference")
+        return (center, wh, obj, cls, head) if return_head else (center, wh, obj, cls)
+
+    @staticmethod
     def filter_boxes(transformed_predictions):
         """(center, wh, obj, class_probs) -> (boxes, scores, classes, nms_indexes) as numpy
         arrays of per-image arrays (detect_net.py:90-146)."""

@@ -124,6 +124,21 @@ int yp_predict_transform_reference(const float *d_pred, int batch, int grid_h, i
                                    float *d_center, float *d_wh, float *d_obj, float *d_cls,
                                    void *stream);
 
+/* The head's producer with the decode in its epilogue: detect_net.py:67-68 (Dense(H*W*A*(5+C),
+ * relu) on the flattened features) followed by detect_net.py:152-183 without storing the raw head
+ * in between.  head[b, j] = relu(d_bias[j] + sum_f d_features[b, f] * d_weight[f, j]), summed in
+ * the order f = 0, 1, ... in binary32 (a plain dot product per output: this entry shows the
+ * epilogue hook csrc/yp_epilogue.h offers to whatever kernel produces the head; it is not a
+ * tuned GEMM, and the model itself is outside this library).  d_features (B, F), d_weight
+ * (F, H*W*A*(5+C)) row-major, d_bias (H*W*A*(5+C)); num_classes must be 5.  Outputs as
+ * yp_predict_transform_reference, equal bit for bit to that entry applied to the stored head;
+ * d_raw, if not NULL, receives the head (B, H*W*A*(5+C)) as well. */
+int yp_dense_relu_predict_transform_reference(const float *d_features, const float *d_weight,
+                                              const float *d_bias, int batch, int features, int grid_h,
+                                              int grid_w, int num_anchors, int num_classes,
+                                              const float *anchors, float *d_raw, float *d_center,
+                                              float *d_wh, float *d_obj, float *d_cls, void *stream);
+
 /* YOLOv3 predict_transform for 1..YP_MAX_HEADS heads in ONE launch (not in the reference;
  * see the mode note above).  Output rows (B, N, 5+C), N = sum_h gh*gw*A, heads
  * concatenated in array order, row index inside a head (row*gw+col)*A + a, row =

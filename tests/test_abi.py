@@ -222,7 +222,8 @@ def test_flag_policy_of_the_python_engines(pkg):
     assert util._dense_nms(None, 0.001, 151200, 5) is True
     assert util._dense_nms(None, 0.001, 10647, 5) is True
     assert util._dense_nms(None, 0.001, 10647, 80) is False       # few anchors per class
-    assert util._dense_nms(None, 0.5, 151200, 5) is False
+    assert util._dense_nms(None, 0.5, 151200, 5) is True           # 1920x1280: thousands per segment at any threshold
+    assert util._dense_nms(None, 0.5, 22743, 5) is False and util._dense_nms(None, 0.5, 10647, 5) is False
     assert util._dense_nms(False, 0.001, 151200, 5) is False and util._dense_nms(True, 0.9, 10, 5) is True
     p = util._v3_params(4, 5, 0.5, 0.4)
     assert (p.mode, p.batch, p.num_classes, p.max_out, p.flags) == (L.YP_MODE_YOLOV3, 4, 5, 0, 0)
