@@ -355,6 +355,7 @@ class YoloV3PostMulti:
             if len(self._desc_cache) > 64:
                 self._desc_cache.clear()
             self._desc_cache[key] = descs
+        stream_obj = stream
         stream = _lib.stream_ptr(self.device) if stream is None else stream.cuda_stream
         with _lib.on_device(self.device):
             rc = self._lib.yp_detect_yolov3_multi(
@@ -364,7 +365,8 @@ class YoloV3PostMulti:
         if rc != 0:
             _lib.check(rc, "yp_detect_yolov3_multi")
         if n < self.n_sets:      # the sets this call did not use read as empty, not as the last call's
-            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+            with torch.cuda.stream(stream_obj if stream_obj is not None
+                                   else torch.cuda.current_stream(self.device)):
                 self.count[n:].zero_()
         return self.out, self.count
 
