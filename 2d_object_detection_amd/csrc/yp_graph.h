@@ -49,6 +49,7 @@ constexpr int kGraphEdges = 8;            // recorded suppressors per column (th
 constexpr int kGraphRowTile = 128;
 constexpr int kGraphPairWaves = 4;
 constexpr int kGraphWaveModeMax = 8192;   // segments up to this size: one batch per wave of k_graph_pairs
+constexpr int kGraphListCache = 512;      // graph segments whose sizes k_graph_pairs keeps in LDS
 constexpr int kGraphThreads = 256;        // k_graph_pairs workgroup
 constexpr int kGraphWaves = kGraphThreads / 64;
 constexpr int kGraphRanges = 64;          // bin ranges a wave looks up per pass
@@ -398,6 +399,7 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
 {
     __shared__ GraphWaveShared s_ws[kGraphWaves];
     __shared__ GraphSeg s_gs;
+    __shared__ int s_k[kGraphListCache];
     const int n_graph = ctrl[1];                    // graph segments of this launch
     if (n_graph == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -411,15 +413,22 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
     // (Measured per 32 images at 1920x1280: 2 000 candidates per segment 324 -> 232 us with a batch
     // per wave; 29 500 per segment 4.57 ms shared, 5.12 ms with a batch per wave.)
     const bool spare = ctrl[2] * (64 / kGraphCols) >= 4 * (int)gridDim.x;
+    // (the segments' sizes once, in LDS: the loop below looks at every segment and takes part in
+    // few of them, and two dependent trips to memory per look would be most of its time)
+    const bool cached = n_graph <= kGraphListCache;
+    if (cached) {
+        for (int i = threadIdx.x; i < n_graph; i += kGraphThreads) s_k[i] = a.gseg[a.glist[i]].K;
+        __syncthreads();
+    }
     for (int t = 0; t < n_graph; ++t) {
-        const int seg = a.glist[t];
         // nothing for this workgroup in this segment: on to the next (uniform, before any barrier)
-        const int K = a.gseg[seg].K;
+        const int K = __builtin_amdgcn_readfirstlane(cached ? s_k[t] : a.gseg[a.glist[t]].K);
         const bool wave_mode = spare && K <= kGraphWaveModeMax;
         const int per_wg = wave_mode ? kGraphWaves : 1;
         const int n_batches = (K + kGraphCols - 1) / kGraphCols;
         const int start = (int)((blockIdx.x + (unsigned)t * 37u) % gridDim.x);
         if (start * per_wg >= n_batches) continue;
+        const int seg = a.glist[t];
         __syncthreads();                            // everyone is done with the previous s_gs
         {
             const int *src = reinterpret_cast<const int *>(a.gseg + seg);
