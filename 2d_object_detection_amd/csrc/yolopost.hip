@@ -2591,8 +2591,15 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
     const bool per_image = p->num_classes <= kImgMaxClasses && tpi <= kImgMaxTiles &&
                            n_sets * p->batch >= image_path_min_images() && yp_make_thr(p->nms_thr).fast;
     if (per_image) s.img_flag = w.img_flag;
-    if ((stages & 2) && per_image)
-        YP_LAUNCH(5, k_image_nms<YP_MODE_YOLOV3>, dim3(n_sets * p->batch), dim3(kImgThreads), 0, st, s);
+    if ((stages & 2) && per_image) {
+        const dim3 ig(n_sets * p->batch);
+        if (tpi <= kImgSmallTiles)
+            YP_LAUNCH(5, (k_image_nms<YP_MODE_YOLOV3, kImgThreads, kImgCapSmall, kImgPoolSmall>), ig,
+                      dim3(kImgThreads), 0, st, s);
+        else
+            YP_LAUNCH(5, (k_image_nms<YP_MODE_YOLOV3, kImgThreads, kImgCapLarge, kImgPoolLarge>), ig,
+                      dim3(kImgThreads), 0, st, s);
+    }
     if (stages & 2)
         YP_LAUNCH(1, k_segment_nms<YP_MODE_YOLOV3>, dim3(n_seg), dim3(kSegThreads), 0, st, s);
     if ((stages & 2) && dense) {
