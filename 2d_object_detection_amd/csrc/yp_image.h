@@ -25,9 +25,9 @@
 //            all classes at the same time, and writes the kept slots.
 //
 // Classes whose masks do not fit the pool together are handled in groups, one after the other.
-// An image that does not fit (more than kImgCap candidates, a class beyond its region, two equal
-// objectness values inside a class, a box with x2 < x1 or a non-finite area) is flagged in img_flag and left to k_segment_nms, which
-// runs after this kernel and skips the images this kernel finished.  Outputs are exactly the
+// An image that does not fit (more candidates than the kernel's capacity, a class beyond its
+// region, a box with x2 < x1 or a non-finite area) is flagged in img_flag and left to
+// k_segment_nms, which runs after this kernel and skips the images this kernel finished.  Outputs are exactly the
 // arrays k_segment_nms writes (kept_slot, seg_kept, seg_cand, seg_region, seg_pairs, seg_ties).
 #pragma once
 
@@ -280,10 +280,11 @@ void k_image_nms(SegArgs s)
     const YpThr thr = yp_make_thr(s.thr);
 
     // ---- rank sort inside every class: a task is 64 elements of one class against all its keys.
-    // Only the 32 key bits are compared.  Equal objectness values inside a class (saturated
-    // sigmoids) would have to be ordered by slot; they give two elements the same rank instead,
-    // some position stays unwritten, and the image goes to k_segment_nms, which sorts 64-bit keys.
-    {
+    // Only the 32 key bits are compared at first.  Equal objectness values inside a class have to
+    // be ordered by slot; compared by key alone they get the same rank, some position stays
+    // unwritten (still -1), and the sort is repeated with the slot as the tie-break -- for about
+    // one image in a hundred at 140 candidates per class (the keys are binary32 values in (0.5, 1)).
+    auto rank_sort = [&](const bool exact) {
         const int n_tasks = img_tasks(p_all);
         for (int k = wv; k < n_tasks; k += kImgWaves) {
             const int t = __builtin_amdgcn_readfirstlane(s_tasks[k]);
@@ -293,20 +294,39 @@ void k_image_nms(SegArgs s)
             const unsigned int *in = pool32 + 2 * c * cs;
             const int e = (w << 6) + lane;
             const unsigned int mine = e < kc ? in[e] : 0u;
-            const int4 *in4 = reinterpret_cast<const int4 *>(in);
-            const int kp = (kc + 7) & ~7;
+            const unsigned int my_slot = e < kc ? in[cs + e] : 0u;
             int rank = 0;
-            for (int j = 0; j < kp; j += 8) {
-                const int4 q0 = in4[j >> 2], q1 = in4[(j >> 2) + 1];
-                rank += ((unsigned int)q0.x < mine) + ((unsigned int)q0.y < mine) +
-                        ((unsigned int)q0.z < mine) + ((unsigned int)q0.w < mine);
-                rank += ((unsigned int)q1.x < mine) + ((unsigned int)q1.y < mine) +
-                        ((unsigned int)q1.z < mine) + ((unsigned int)q1.w < mine);
+            if (!exact) {
+                const int4 *in4 = reinterpret_cast<const int4 *>(in);
+                const int kp = (kc + 7) & ~7;
+                for (int j = 0; j < kp; j += 8) {
+                    const int4 q0 = in4[j >> 2], q1 = in4[(j >> 2) + 1];
+                    rank += ((unsigned int)q0.x < mine) + ((unsigned int)q0.y < mine) +
+                            ((unsigned int)q0.z < mine) + ((unsigned int)q0.w < mine);
+                    rank += ((unsigned int)q1.x < mine) + ((unsigned int)q1.y < mine) +
+                            ((unsigned int)q1.z < mine) + ((unsigned int)q1.w < mine);
+                }
+            } else {
+                for (int j = 0; j < kc; ++j) {      // (rare: a plain loop)
+                    const unsigned int kj = in[j], sj = in[cs + j];
+                    rank += (kj < mine) || (kj == mine && sj < my_slot);
+                }
             }
-            if (e < kc) s_slot[base + rank] = (int)in[cs + e];
+            if (e < kc) s_slot[base + rank] = (int)my_slot;
         }
+    };
+    rank_sort(false);
+    __syncthreads();
+    {
+        bool hole = false;
+        for (int i = tid; i < k_img; i += kImgThreads) hole = hole || s_slot[i] < 0;
+        if (hole) atomicOr(&s_flag, 2);
     }
     __syncthreads();
+    if (s_flag & 2) {       // (uniform)
+        rank_sort(true);
+        __syncthreads();
+    }
     STAMP(3);
 
     // ---- the sorted boxes of all classes, prepared for the pair tests; the packed test needs
@@ -333,7 +353,7 @@ void k_image_nms(SegArgs s)
         if (!safe) atomicOr(&s_flag, 1);
     }
     __syncthreads();
-    if (s_flag != 0) {
+    if (s_flag & 1) {
         if (tid == 0) s.img_flag[b] = 1;
         return;
     }

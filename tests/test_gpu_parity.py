@@ -250,6 +250,28 @@ def test_ref_large_segment_all_survive(pkg, dev, monkeypatch):
         assert_ref_equal(DN.detect(pred.to(dev)), want, 3)
 
 
+def test_v3_ties_in_the_sort_key_of_small_segments(pkg, dev):
+    """Equal objectness values inside an (image, class) segment of a few hundred candidates: the
+    order among them is the anchor order.  (The per-image NMS kernel sorts by the 32 key bits first
+    and repeats the sort with the slot as tie-break when two keys collide.)"""
+    util = pkg.util
+    rs = np.random.RandomState(21)
+    B, N, C = 3, 900, 3
+    rows = np.zeros((B, N, 5 + C), np.float32)
+    rows[:, :, 0] = rs.uniform(0, 400, (B, N))
+    rows[:, :, 1] = rs.uniform(0, 400, (B, N))
+    rows[:, :, 2] = rs.uniform(8, 90, (B, N))
+    rows[:, :, 3] = rs.uniform(8, 90, (B, N))
+    rows[:, :, 4] = rs.choice(np.float32([0.6, 0.7, 0.8, 0.9, 0.95]), (B, N))      # five distinct scores only
+    rows[0, :, 4] = np.float32(0.77)                                              # image 0: all equal
+    cls = rs.randint(0, C, (B, N))
+    rows[np.arange(B)[:, None], np.arange(N)[None, :], 5 + cls] = 0.9
+    want, surv, _ = oracle.n_write_results(rows, 0.5, C, 0.4)
+    assert surv.max() < 512 and want.shape[0] > 100
+    got = util.write_results(torch.from_numpy(rows).to(dev), 0.5, C, 0.4).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
 def test_v3_empty_result_returns_zero(pkg, dev):
     util = pkg.util
     pred = torch.zeros((2, 100, 10), device=dev)

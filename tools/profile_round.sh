@@ -1,22 +1,44 @@
 # Collects the profiles that back the bench line: rocprofv3 kernel statistics of the default
-# bench command and, in separate passes, the HBM traffic counters of the same command; then the
-# large-segment NMS path at cfg5 and cfg3 (kernel statistics + per-kernel HIP-event breakdown) and
-# one bench line over RCCL with a world of one rank.  Run on the GPU box from the repository root;
-# results land under gpurun_out/prof_final (copy what is to be kept into profiles/).
-# Every GPU step runs under its own time limit and the script stops at the first failure.
+# bench command (8 batches per launch, two launches in flight) and of the same loop with one launch
+# at a time, the HBM traffic and instruction counters in separate passes, one bench line per
+# configuration, the large-segment NMS path at cfg5 and cfg3 (kernel statistics + per-kernel
+# HIP-event breakdown), the in-kernel phase stamps of the per-image NMS kernel, and one bench line
+# over RCCL with a world of one rank.  Run on the GPU box from the repository root; results land
+# under gpurun_out/prof_final (copy what is to be kept into profiles/).  Every GPU step runs under its
+# own time limit and the script stops at the first failure.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/prof_final
 rm -rf $OUT && mkdir -p $OUT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 2 > $OUT/pmc_$c.log 2>&1
-done
-python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_summary.json
-timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_1 -- python3 bench.py --no-cpu-baseline --in-flight 1 > $OUT/stats_1.log 2>&1
+find $OUT/stats_1 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_in_flight_1.csv \;
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 bench.py --no-cpu-baseline --steps 24 --warmup 8 --repeats 3 > $OUT/pmc_$c.log 2>&1
+done
+python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_fetch_write.json
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -- python3 bench.py --no-cpu-baseline --steps 24 --warmup 8 --repeats 3 > $OUT/pmc_sq.log 2>&1
+python3 tools/pmc_summary.py $OUT/pmc_sq > $OUT/pmc_sq_instruction_counters.json
+timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout -k 10 300 python3 bench.py --in-flight 1 --no-cpu-baseline > $OUT/bench_in_flight_1.json 2>> $OUT/bench.err
 tail -1 $OUT/bench.json | cut -c1-300
-head -8 $OUT/kernel_stats.csv
+head -6 $OUT/kernel_stats.csv | cut -c1-160
+# one line per configuration
+: > $OUT/all_configs_bench.jsonl
+for cfg in cfg1 cfg2 "cfg2 --clustered" cfg3 "cfg3 --clustered" cfg4 cfg5; do
+  timeout -k 10 300 python3 bench.py --no-cpu-baseline --config $cfg --steps 40 --warmup 8 --repeats 5 >> $OUT/all_configs_bench.jsonl 2>> $OUT/bench.err
+done
+python3 - $OUT/all_configs_bench.jsonl > $OUT/all_configs_summary.txt <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    d = json.loads(l); k = d["kernels_ms"]; c = d["config"]
+    print("%-44s %10.1f img/s step %8.5f ms | per launch of %d: front %.4f nms %.4f gather %.4f (alone %.4f %.4f %.4f) | frac %.3f alone %.3f | surv/img %.0f kept %.0f ties %d | latency one call %s us"
+          % (c["workload"][:44], d["value"], d["ms_per_step"], c["batches_per_launch"], k["front"], k["segment_nms"], k["gather"],
+             k["alone"]["front"], k["alone"]["segment_nms"], k["alone"]["gather"], d["roofline"]["frac"], d["roofline"]["frac_alone"],
+             c["survivors_per_image"], c["kept_per_image"], c["iou_threshold_ties_per_batch"], d["latency_us"]["one_batch"]["median"]))
+PY
+cat $OUT/all_configs_summary.txt
 # large segments: graph path
 for cfg in cfg5 cfg3; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$cfg -- python3 bench.py --no-cpu-baseline --config $cfg --steps 8 --warmup 2 --repeats 3 > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
@@ -25,7 +47,17 @@ done
 CONF=0.001 timeout -k 10 120 python3 tools/nms_breakdown.py > $OUT/nms_breakdown.txt 2>&1
 CONF=0.5 timeout -k 10 120 python3 tools/nms_breakdown.py >> $OUT/nms_breakdown.txt 2>&1
 CONF=0.5 CLUSTERED=1 timeout -k 10 120 python3 tools/nms_breakdown.py >> $OUT/nms_breakdown.txt 2>&1
+DENSE=0 CONF=0.5 timeout -k 10 120 python3 tools/nms_breakdown.py >> $OUT/nms_breakdown.txt 2>&1
+DENSE=0 CONF=0.5 CLUSTERED=1 timeout -k 10 120 python3 tools/nms_breakdown.py >> $OUT/nms_breakdown.txt 2>&1
 cat $OUT/nms_breakdown.txt
-# the multi-rank code path (process group, barriers, one all-gather per launch) with one rank on RCCL
+timeout -k 10 120 python3 tools/latency_sweep.py > $OUT/latency_sweep.txt 2>&1
+cat $OUT/latency_sweep.txt
+if [ -f 2d_object_detection_amd/libyolopost_stamps.so ]; then
+  YOLOPOST_LIB=$PWD/2d_object_detection_amd/libyolopost_stamps.so timeout -k 10 120 python3 tools/img_stamps.py > $OUT/image_nms_phase_stamps.txt 2>&1
+  INP=608 YOLOPOST_LIB=$PWD/2d_object_detection_amd/libyolopost_stamps.so timeout -k 10 120 python3 tools/img_stamps.py >> $OUT/image_nms_phase_stamps.txt 2>&1
+  cat $OUT/image_nms_phase_stamps.txt
+fi
+# the multi-rank code path (process group, barriers, all-gathers) with one rank on RCCL
 YP_BENCH_FORCE_DIST=1 YP_BENCH_WATCHDOG=120 timeout -k 10 200 python3 bench.py --no-cpu-baseline > $OUT/bench_rccl_world1.json 2> $OUT/bench_rccl_world1.err
-tail -1 $OUT/bench_rccl_world1.json | cut -c1-300
+YP_BENCH_FORCE_DIST=1 YP_BENCH_WATCHDOG=120 timeout -k 10 200 python3 bench.py --no-cpu-baseline --exchange-every 4 > $OUT/bench_rccl_world1_exchange_every_4.json 2>> $OUT/bench_rccl_world1.err
+tail -1 $OUT/bench_rccl_world1.json | cut -c1-200
