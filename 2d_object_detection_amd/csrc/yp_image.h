@@ -168,6 +168,7 @@ void k_image_nms(SegArgs s)
     __shared__ int s_cnt[kImgMaxClasses];      // candidates per class
     __shared__ unsigned int s_tiesc[kImgMaxClasses];
     __shared__ int s_flag;                     // the image is left to k_segment_nms
+    __shared__ int s_ties_in;                  // bit c: class c has two candidates of equal objectness
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -190,7 +191,10 @@ void k_image_nms(SegArgs s)
         s_cnt[tid] = 0;
         s_tiesc[tid] = 0u;
     }
-    if (tid == 0) s_flag = 0;
+    if (tid == 0) {
+        s_flag = 0;
+        s_ties_in = 0;
+    }
     // (a sorted position nobody writes keeps its -1: two candidates of a class had equal keys)
     for (int i = tid; i < kImgCap; i += kImgThreads) s_slot[i] = -1;
     __syncthreads();
@@ -284,21 +288,23 @@ void k_image_nms(SegArgs s)
     // be ordered by slot; compared by key alone they get the same rank, some position stays
     // unwritten (still -1), and the sort is repeated with the slot as the tie-break -- for about
     // one image in a hundred at 140 candidates per class (the keys are binary32 values in (0.5, 1)).
-    auto rank_sort = [&](const bool exact) {
+    auto rank_sort = [&](const bool exact, const unsigned int classes) {
         const int n_tasks = img_tasks(p_all);
         for (int k = wv; k < n_tasks; k += kImgWaves) {
             const int t = __builtin_amdgcn_readfirstlane(s_tasks[k]);
             const int c = t >> 4, w = (t & 15) >> 1;
+            if (!((classes >> c) & 1u)) continue;
             const int kc = __builtin_amdgcn_readfirstlane(s_cnt[c]);
             const int base = img_cand(s_pref[c << 4]);
             const unsigned int *in = pool32 + 2 * c * cs;
             const int e = (w << 6) + lane;
             const unsigned int mine = e < kc ? in[e] : 0u;
             const unsigned int my_slot = e < kc ? in[cs + e] : 0u;
+            const int4 *in4 = reinterpret_cast<const int4 *>(in);
+            const int4 *sl4 = reinterpret_cast<const int4 *>(in + cs);
+            const int kp = (kc + 7) & ~7;
             int rank = 0;
             if (!exact) {
-                const int4 *in4 = reinterpret_cast<const int4 *>(in);
-                const int kp = (kc + 7) & ~7;
                 for (int j = 0; j < kp; j += 8) {
                     const int4 q0 = in4[j >> 2], q1 = in4[(j >> 2) + 1];
                     rank += ((unsigned int)q0.x < mine) + ((unsigned int)q0.y < mine) +
@@ -307,24 +313,31 @@ void k_image_nms(SegArgs s)
                             ((unsigned int)q1.z < mine) + ((unsigned int)q1.w < mine);
                 }
             } else {
-                for (int j = 0; j < kc; ++j) {      // (rare: a plain loop)
-                    const unsigned int kj = in[j], sj = in[cs + j];
-                    rank += (kj < mine) || (kj == mine && sj < my_slot);
+                // (key, slot) pairs in lexicographic order; the padding keys are larger than any key,
+                // whatever the slot words behind the class's candidates hold
+                auto before = [&](int kj, int sj) {
+                    return ((unsigned int)kj < mine) | (((unsigned int)kj == mine) & ((unsigned int)sj < my_slot));
+                };
+                for (int j = 0; j < kp; j += 4) {
+                    const int4 q = in4[j >> 2], r = sl4[j >> 2];
+                    rank += before(q.x, r.x) + before(q.y, r.y) + before(q.z, r.z) + before(q.w, r.w);
                 }
             }
             if (e < kc) s_slot[base + rank] = (int)my_slot;
         }
     };
-    rank_sort(false);
+    rank_sort(false, ~0u);
     __syncthreads();
-    {
-        bool hole = false;
-        for (int i = tid; i < k_img; i += kImgThreads) hole = hole || s_slot[i] < 0;
-        if (hole) atomicOr(&s_flag, 2);
+    for (int i = tid; i < k_img; i += kImgThreads) {
+        if (s_slot[i] < 0) {            // the class that owns position i had two equal keys
+            int c = 0;
+            while (c + 1 < C && img_cand(s_pref[(c + 1) << 4]) <= i) ++c;
+            atomicOr(&s_ties_in, (int)(1u << c));
+        }
     }
     __syncthreads();
-    if (s_flag & 2) {       // (uniform)
-        rank_sort(true);
+    if (s_ties_in != 0) {               // (uniform) those classes once more, the slot as tie-break
+        rank_sort(true, (unsigned int)s_ties_in);
         __syncthreads();
     }
     STAMP(3);
@@ -353,7 +366,7 @@ void k_image_nms(SegArgs s)
         if (!safe) atomicOr(&s_flag, 1);
     }
     __syncthreads();
-    if (s_flag & 1) {
+    if (s_flag != 0) {
         if (tid == 0) s.img_flag[b] = 1;
         return;
     }

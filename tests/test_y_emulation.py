@@ -213,6 +213,34 @@ def test_emulated_write_results_on_decoded_rows(pkg, emu):
     assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
 
 
+def test_emulated_write_results_with_equal_scores(pkg, emu):
+    """Equal objectness values inside small (image, class) segments: both NMS kernels order them by
+    anchor index (the per-image kernel by repeating its 32-bit sort with the slot as tie-break)."""
+    util = pkg.util
+    rs = np.random.RandomState(21)
+    B, N, C = 2, 300, 3
+    rows = np.zeros((B, N, 5 + C), np.float32)
+    rows[:, :, 0], rows[:, :, 1] = rs.uniform(0, 200, (B, N)), rs.uniform(0, 200, (B, N))
+    rows[:, :, 2], rows[:, :, 3] = rs.uniform(8, 60, (B, N)), rs.uniform(8, 60, (B, N))
+    rows[:, :, 4] = rs.choice(np.float32([0.6, 0.7, 0.8]), (B, N))
+    rows[0, :, 4] = np.float32(0.77)
+    rows[np.arange(B)[:, None], np.arange(N)[None, :], 5 + rs.randint(0, C, (B, N))] = 0.9
+    rows = np.ascontiguousarray(rows)
+    want, surv, _ = oracle.n_write_results(rows, 0.5, C, 0.4)
+    assert surv.max() < 512 and want.shape[0] > 50
+    p = util._v3_params(B, C, 0.5, 0.4)
+    need = emu.yp_rows_workspace_bytes(B, N, C)
+    ws = aligned(need, fill=0xA5)
+    out = aligned(B * N * 32, 16).view(np.float32).reshape(B * N, 8)
+    n = np.zeros(1, np.int32)
+    rc = emu.yp_write_results(rows.ctypes.data, N, ctypes.byref(p), out.ctypes.data, B * N, n.ctypes.data, None,
+                              ws.ctypes.data, need, None)
+    assert rc == 0 and n[0] == len(want)
+    assert np.array_equal(out[:n[0]], want)
+    c = emul_counters(emu)
+    assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
+
+
 def test_emulated_reference_mode(pkg, emu):
     """yp_detect_reference (detect_net.py:90-183 in one pass) against the oracle."""
     L, P = pkg._lib, pkg.params
