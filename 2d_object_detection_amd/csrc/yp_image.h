@@ -33,10 +33,11 @@
 
 constexpr int kImgMaxClasses = 32;            // classes an image may have on this path
 constexpr int kImgMaxTiles = 256;             // candidate tiles per image beyond which it is not tried
-// Launches with fewer images stay with k_segment_nms: one workgroup per image needs about 27 us
-// whatever the launch size, so it pays once the images fill the GPU (measured on an MI355X: 256
-// images 38 us against 32 us for the segment kernel alone, 512 images 40 against 55; with several
-// launches in flight the smaller instruction count of this kernel wins from 256 images on).
+// Launches with fewer images stay with k_segment_nms: one workgroup per image lives about 33 us
+// whatever the launch size, so it pays once the images fill the GPU (measured on an MI355X with
+// 714 candidates per image: 256 images 42 us against 32 us for the segment kernel when the launch
+// has the GPU to itself, 512 images 44 against 62; with two launches in flight the smaller
+// instruction count of this kernel wins from 256 images on).
 // The environment variable YP_IMG_MIN_IMAGES overrides it (the tests use 1 and a huge value to
 // run every case on both paths).
 constexpr int kImgMinImages = 256;
