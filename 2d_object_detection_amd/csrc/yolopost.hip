@@ -1090,6 +1090,67 @@ __device__ __forceinline__ void suppress_words(const YpPrep &pi, bool row_ok, co
     for (int u = 0; u < U; ++u) words[u] = __ballot(verdict[u] == 1);
 }
 
+// two binary32 values that are added and multiplied together (one packed instruction on gfx950)
+#if defined(__clang__)
+typedef float yp_f2 __attribute__((ext_vector_type(2)));
+#else
+typedef float yp_f2 __attribute__((vector_size(8)));
+#endif
+
+// Two columns a, b against one row per lane, two tests per packed instruction.  was / wbs: bit l
+// set when lane l's row suppresses the column (a, b may be uniform over the wave or differ from
+// lane to lane).  The arithmetic is yp_suppress_pretest's for boxes whose
+// union is known to be positive (x2 >= x1, y2 >= y1, finite areas: checked when the boxes were
+// loaded) and a threshold inside the guard-band range; rows in ca_rows / cb_rows whose quotient
+// the bands leave undecided take the exact divide-and-compare and are counted as ties.
+template <int MODE>
+__device__ __forceinline__ void pair2_words(const float4 &ri, float ai, const float4 &ca,
+                                          const float4 &cb, float aa, float ab, const YpThr &thr,
+                                          u64 ca_rows, u64 cb_rows, u64 &was, u64 &wbs,
+                                          unsigned int &ties)
+{
+    const float plus1 = MODE == YP_MODE_YOLOV3 ? 1.0f : 0.0f;
+    const yp_f2 lo0 = {vmax(ri.x, ca.x), vmax(ri.x, cb.x)};
+    const yp_f2 lo1 = {vmax(ri.y, ca.y), vmax(ri.y, cb.y)};
+    const yp_f2 hi0 = {vmin(ri.z, ca.z), vmin(ri.z, cb.z)};
+    const yp_f2 hi1 = {vmin(ri.w, ca.w), vmin(ri.w, cb.w)};
+    yp_f2 d0 = hi0 - lo0;
+    yp_f2 d1 = hi1 - lo1;
+    d0 = d0 + plus1;
+    d1 = d1 + plus1;
+    d0[0] = vmax(d0[0], 0.0f);
+    d0[1] = vmax(d0[1], 0.0f);
+    d1[0] = vmax(d1[0], 0.0f);
+    d1[1] = vmax(d1[1], 0.0f);
+    const yp_f2 inter = d0 * d1;
+    const yp_f2 aj = {aa, ab};
+    yp_f2 uni = ai + aj;
+    uni = uni - inter;
+    const yp_f2 t_hi = uni * thr.hi;
+    const yp_f2 t_lo = uni * thr.lo;
+    u64 ya = __ballot(inter[0] > t_hi[0]);
+    u64 yb = __ballot(inter[1] > t_hi[1]);
+    const u64 na = __ballot(inter[0] < t_lo[0]);
+    const u64 nb = __ballot(inter[1] < t_lo[1]);
+    const u64 ua = ~(ya | na) & ca_rows;
+    const u64 ub = ~(yb | nb) & cb_rows;
+    if ((ua | ub) != 0ull) {   // rare: some quotient sits within 2^-20 of the threshold
+        const int lane = threadIdx.x & 63;
+        const YpPrep pi = {ri.x, ri.y, ri.z, ri.w, ai};
+        const YpPrep pa = {ca.x, ca.y, ca.z, ca.w, aa};
+        const YpPrep pb = {cb.x, cb.y, cb.z, cb.w, ab};
+        const bool ea = ((ua >> lane) & 1ull) && yp_suppresses_exact<MODE>(pi, pa, thr.thr);
+        const bool eb = ((ub >> lane) & 1ull) && yp_suppresses_exact<MODE>(pi, pb, thr.thr);
+        const u64 xa = __ballot(ea);
+        const u64 xb = __ballot(eb);
+        ya = (ya & ~ua) | xa;
+        yb = (yb & ~ub) | xb;
+        ties += (unsigned int)(__popcll(ua) + __popcll(ub));
+    }
+    was = ya & ca_rows;
+    wbs = yb & cb_rows;
+}
+
 template <int MODE, class Emit>
 __device__ __forceinline__ int nms_chunks(const float4 *sbox, unsigned char *removed, int K,
                                           const YpThr thr, int max_out, ChunkShared &sh,
@@ -1798,9 +1859,10 @@ __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vbl
                 const float w = c4.z - c4.x + 1.0f, h = c4.w - c4.y + 1.0f;
                 const float size = w > h ? w : h;
                 const float cx = 0.5f * (c4.x + c4.z), cy = 0.5f * (c4.y + c4.w);
-                // (comparisons that a NaN fails)
-                ok = ok && (w > 0.0f) && (h > 0.0f) && (size < 1e30f) && (__builtin_fabsf(cx) < 1e30f) &&
-                     (__builtin_fabsf(cy) < 1e30f);
+                // (comparisons that a NaN fails; ordered corners make every width and height >= 1,
+                // which with a finite area is what the packed pair test of the graph kernels assumes)
+                ok = ok && (c4.z >= c4.x) && (c4.w >= c4.y) && (w * h < 1e30f) && (size < 1e30f) &&
+                     (__builtin_fabsf(cx) < 1e30f) && (__builtin_fabsf(cy) < 1e30f);
                 xlo = vmin(xlo, cx); xhi = vmax(xhi, cx);
                 ylo = vmin(ylo, cy); yhi = vmax(yhi, cy);
                 mlo = vmin(mlo, size); mhi = vmax(mhi, size);
@@ -2625,6 +2687,7 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
         ga.seg_pairs = w.seg_pairs;
         ga.seg_ties = w.seg_ties;
         ga.work = reinterpret_cast<int *>(w.sbox);
+        ga.dbg = g_dbg ? g_dbg + (size_t)n_seg * 32 : nullptr;   // (diagnostic build: one row behind the segments')
         // pair tests: a fixed number of workgroups that share out the batches of all graph
         // segments; resolve: one workgroup per graph segment (those beyond their number leave)
         const long long slots_all = (long long)n_seg / p->num_classes * spi;

@@ -46,7 +46,7 @@ constexpr int kGraphEdges = 8;            // recorded suppressors per column (th
 // 1920x1280: tiles of 256 rows at 3 waves per SIMD 4.47 ms / 368 us / 1.10 ms (29 500 candidates
 // per segment / 2 000 / clustered scenes), 128 rows at 4 waves 4.57 ms / 324 us / 0.95 ms, 64 rows
 // at 4 waves 4.80 ms / 309 us / 0.89 ms.
-constexpr int kGraphRowTile = 128;
+constexpr int kGraphRowTile = 64;
 constexpr int kGraphPairWaves = 4;
 constexpr int kGraphWaveModeMax = 8192;   // segments up to this size: one batch per wave of k_graph_pairs
 constexpr int kGraphListCache = 512;      // graph segments whose sizes k_graph_pairs keeps in LDS
@@ -90,7 +90,22 @@ struct GraphArgs {
     unsigned int *seg_ties;      // [n_seg]
     int *work;                   // [4 * B*spi] two work lists per segment (the sorted-box area, which
                                  // nothing reads after the index was built)
+    unsigned long long *dbg;     // diagnostic builds only (YP_STAMPS): 16 counters of k_graph_pairs
 };
+
+// Diagnostic build: wave-clock ticks per phase of a walk, summed over the waves of the launch.
+#ifdef YP_STAMPS
+#define GW_T(k)                                                \
+    do {                                                       \
+        const unsigned int tn_ = (unsigned int)__builtin_readcyclecounter(); \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&ws.dbg[k], tn_ - gw_prev); \
+        gw_prev = tn_;                                         \
+    } while (0)
+#define GW_N(k, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&ws.dbg[k], (unsigned int)(n)); } while (0)
+#else
+#define GW_T(k) do { } while (0)
+#define GW_N(k, n) do { } while (0)
+#endif
 
 // Size of a box for the class test: the larger of the width and height terms the IoU uses.
 template <int MODE>
@@ -165,6 +180,9 @@ struct GraphWaveShared {
     int pc[kGraphBuf];              // index position | size class << 24
     int rbeg[kGraphRanges];         // bin ranges of the current pass: first index position
     int rpre[kGraphRanges + 1];     // exclusive prefix of their lengths
+#ifdef YP_STAMPS
+    unsigned int dbg[12];           // diagnostic build: ticks per phase
+#endif
 };
 
 // Records "the row ranked `suppressor` suppresses the box at index position `target`": the
@@ -192,6 +210,8 @@ __device__ __forceinline__ void graph_record(int *gcnt, int *gedge, int target, 
 // suppressed themselves: smaller and larger classes, rows with status kSuppressed left out.
 // Per lane the count is returned, the ranks go to `edge_out` (the earliest in [0], then up to
 // kGraphEdges-1 in the order found), and kept_hit tells that one of them is already kept.
+// (k_graph_pairs passes kGraphEdges words of LDS per lane as `edge_out` too: the suppressors of the
+// lane's own column collect there during the walk.)
 //
 // Candidate rows are looked at by one lane each when they are fetched: a row that cannot touch
 // the batch's bounding box, whose class is out of order for the pair rule, or that is already
@@ -207,11 +227,17 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
                                           int n_split, int *edge_out, unsigned int &pairs,
                                           unsigned int &ties, bool &kept_hit)
 {
+#ifdef YP_STAMPS
+    unsigned int gw_prev = (unsigned int)__builtin_readcyclecounter();
+    GW_N(8, 1);
+#endif
     const int lane = threadIdx.x & 63;
     constexpr int COLS = REBUILD ? 64 : kGraphCols, REP = 64 / COLS;
     const int rslot = REP == 1 ? 0 : lane / COLS;     // which of the REP rows of a step this lane takes
     const YpBox bj = {cj.x, cj.y, cj.z, cj.w};
     const YpPrep pj = yp_prep<MODE>(bj);
+    const float4 rj = make_float4(pj.lo0, pj.lo1, pj.hi0, pj.hi1);
+    const u64 live_mask = __ballot(live);
     // classes and extent of the batch (uniform)
     const int my_class = graph_class(graph_box_size<MODE>(cj), gs.e_min);
     const int cA = wave_min_i(live ? my_class : kGraphClasses), cB = wave_max_i(live ? my_class : -1);
@@ -229,6 +255,8 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
     int n_buf = 0;      // useful rows waiting in LDS (uniform)
     // test the waiting rows against the columns, four (uniform) rows at a time
     auto flush = [&]() {
+        GW_T(4);
+        GW_N(10, (n_buf + 4 * REP - 1) / (4 * REP));
         // pad to a multiple of four (times REP) with rows that cannot record anything
         constexpr int G = 4 * REP;
         if (lane < G) {
@@ -245,36 +273,50 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
         for (int r0 = 0; r0 < n_buf; r0 += G) {
             float4 ci[4];
             float ai[4];
-            int rk[4], pc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int q = r0 + u * REP + rslot;
                 ci[u] = ws.row[q];
                 ai[u] = ws.area[q];
-                rk[u] = ws.rank[q];
-                pc[u] = ws.pc[q];
             }
+            // (packed tests, two rows per instruction: the segment qualified with x2 >= x1, y2 >= y1
+            // and finite areas, so every union is >= 1; the padding rows decide "no")
             u64 words[4];
-            suppress_words<MODE, 4>(pj, live, ci, ai, thr, words, ties);
+            unsigned int nt = 0u;
+            pair2_words<MODE>(rj, pj.area, ci[0], ci[1], ai[0], ai[1], thr, live_mask, live_mask, words[0],
+                              words[1], nt);
+            pair2_words<MODE>(rj, pj.area, ci[2], ci[3], ai[2], ai[3], thr, live_mask, live_mask, words[2],
+                              words[3], nt);
+            ties += lane == 0 ? nt : 0u;
             if ((words[0] | words[1] | words[2] | words[3]) == 0ull) continue;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (words[u] == 0ull) continue;
                 const bool sup = (words[u] >> lane) & 1ull;
+                // (rank and position of the row are only looked up for the few rows that suppress)
+                const int q = r0 + u * REP + rslot;
+                const int rk = ws.rank[q];
                 if (REBUILD) {
                     // only rows ranked before the column count (this also drops the column itself)
-                    if (sup && rk[u] < my_rank) {
-                        if (cnt < kGraphEdges - 1) edge_out[1 + cnt] = rk[u];
-                        first = rk[u] < first ? rk[u] : first;
+                    if (sup && rk < my_rank) {
+                        if (cnt < kGraphEdges - 1) edge_out[1 + cnt] = rk;
+                        first = rk < first ? rk : first;
                         ++cnt;
-                        if (status[rk[u]] == kKept) kept_hit = true;
+                        if (status[rk] == kKept) kept_hit = true;
                     }
                 } else if (sup) {
-                    const int rc = pc[u] >> 24;
-                    if (rk[u] < my_rank) {
-                        if (rc >= my_class) graph_record(gcnt, gedge, my_pos, rk[u]);
-                    } else if (rk[u] > my_rank && rc > my_class) {
-                        graph_record(gcnt, gedge, pc[u] & 0xffffff, my_rank);
+                    const int pc = ws.pc[q];
+                    const int rc = pc >> 24;
+                    if (rk < my_rank) {
+                        // (suppressors of the lane's own column wait in LDS and are recorded together
+                        // when the batch is done: one trip to memory per column instead of one per pair)
+                        if (rc >= my_class) {
+                            if (cnt < kGraphEdges - 1) edge_out[1 + cnt] = rk;
+                            first = rk < first ? rk : first;
+                            ++cnt;
+                        }
+                    } else if (rk > my_rank && rc > my_class) {
+                        graph_record(gcnt, gedge, pc & 0xffffff, my_rank);
                     }
                 }
             }
@@ -283,6 +325,7 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();   // the buffer is refilled
         n_buf = 0;
+        GW_T(5);
     };
 
     // ranges = (class, cell row) pairs in reach, each a run of consecutive cells = one contiguous
@@ -300,7 +343,8 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
     }
     const int w_incl = wave_inclusive_scan(w_n, lane);
     const int n_ranges = __builtin_amdgcn_readlane(w_incl, kGraphClasses - 1);
-    int tile_no = 0;     // candidate tiles of the batch, numbered over all passes
+    GW_T(0);
+    int tile_base = 0;   // candidate tiles of the batch in earlier passes (tiles are numbered over all passes)
     for (int g0 = 0; g0 < n_ranges; g0 += kGraphRanges) {
         // lane l: range g0 + l
         int beg = 0, len = 0;
@@ -335,14 +379,17 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int n_rows = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
-        for (int t0 = 0; t0 < n_rows; t0 += kGraphRowTile, ++tile_no) {
-            if (tile_no % n_split != split) continue;
+        GW_T(1);
+        // The tiles of this pass that are this wave's: tile_base + i with (tile_base + i) % n_split
+        // == split.  The loads of a tile are issued before the tile in front of it is sifted and
+        // tested, so a trip to memory is hidden behind the pair tests instead of waited for.
+        constexpr int T = kGraphRowTile / 64;
+        const int n_tiles = (n_rows + kGraphRowTile - 1) / kGraphRowTile;
+        // element e of the concatenated ranges -> its range by bisection of the prefix
+        auto locate = [&](int t0, int (&src)[T]) {
             const int fill = n_rows - t0 < kGraphRowTile ? n_rows - t0 : kGraphRowTile;
-            // fetch: element e of the concatenated ranges -> its range by bisection of the
-            // prefix; all loads of the tile are in flight together
-            int src[kGraphRowTile / 64];
 #pragma unroll
-            for (int k = 0; k < kGraphRowTile / 64; ++k) {
+            for (int k = 0; k < T; ++k) {
                 const int e = t0 + k * 64 + lane;
                 int lo = 0, hi = kGraphRanges - 1;     // largest l with rpre[l] <= e
 #pragma unroll
@@ -352,16 +399,50 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
                 }
                 src[k] = k * 64 + lane < fill ? ws.rbeg[lo] + (e - ws.rpre[lo]) : 0;
             }
-            float4 c4[kGraphRowTile / 64];
-            int r4[kGraphRowTile / 64];
+        };
+        int i_tile = ((split - tile_base) % n_split + n_split) % n_split;
+        int src_n[T];
+        float4 c4_n[T];
+        int r4_n[T];
+        if (i_tile < n_tiles) {
+            locate(i_tile * kGraphRowTile, src_n);
 #pragma unroll
-            for (int k = 0; k < kGraphRowTile / 64; ++k) {
-                c4[k] = xraw[src[k]];
-                r4[k] = xidx[src[k]];
+            for (int k = 0; k < T; ++k) {
+                c4_n[k] = xraw[src_n[k]];
+                r4_n[k] = xidx[src_n[k]];
             }
+        }
+        GW_T(2);
+        while (i_tile < n_tiles) {
+#ifdef YP_STAMPS
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the tile's loads have landed
+            GW_T(3);
+            GW_N(9, 1);
+#endif
+            const int t0 = i_tile * kGraphRowTile;
+            const int fill = n_rows - t0 < kGraphRowTile ? n_rows - t0 : kGraphRowTile;
+            int src[T];
+            float4 c4[T];
+            int r4[T];
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                src[k] = src_n[k];
+                c4[k] = c4_n[k];
+                r4[k] = r4_n[k];
+            }
+            i_tile += n_split;
+            if (i_tile < n_tiles) {
+                locate(i_tile * kGraphRowTile, src_n);
+#pragma unroll
+                for (int k = 0; k < T; ++k) {
+                    c4_n[k] = xraw[src_n[k]];
+                    r4_n[k] = xidx[src_n[k]];
+                }
+            }
+            GW_T(2);
             // sift and pack
 #pragma unroll
-            for (int k = 0; k < kGraphRowTile / 64; ++k) {
+            for (int k = 0; k < T; ++k) {
                 const int rc = graph_class(graph_box_size<MODE>(c4[k]), gs.e_min);
                 bool useful = k * 64 + lane < fill && !(c4[k].z + gs.margin < bxlo) &&
                               !(c4[k].x - gs.margin > bxhi) && !(c4[k].w + gs.margin < bylo) &&
@@ -379,84 +460,166 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
                 }
                 n_buf += __popcll(m);
             }
+            GW_T(4);
             if (n_buf > 64) flush();     // (room for the next tile: kGraphBuf - 64 >= a tile)
         }
+        tile_base += n_tiles;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();       // the next pass overwrites the ranges
     }
     if (n_buf > 0) flush();
-    if (REBUILD) edge_out[0] = first;
+    if (REBUILD) {
+        edge_out[0] = first;
+    } else if (cnt > 0) {
+        // the column's suppressors of this walk: room for all of them is taken with one atomic
+        const int k0 = atomicAdd(&gcnt[my_pos], cnt);
+        int *e = gedge + (size_t)my_pos * kGraphEdges;
+        const int listed = cnt < kGraphEdges - 1 ? cnt : kGraphEdges - 1;
+        for (int k = 0; k < listed; ++k)
+            if (k0 + k < kGraphEdges - 1) e[1 + k0 + k] = edge_out[1 + k];
+        atomicMin(&e[0], first);
+    }
+    GW_T(6);
     return cnt;
 }
 
-// Pair tests of every graph segment of the launch.  A workgroup takes one batch at a time, its
-// waves share the batch's row tiles; the workgroups walk the list of graph segments and take
-// the batches blockIdx.x, blockIdx.x + gridDim.x, ... of each (rotated from segment to segment
-// so that short segments do not all land on the first workgroups).
+// Pair tests of every graph segment of the launch.  The unit of work is a "group": one batch of
+// a segment whose row tiles the four waves of a workgroup share, or -- for segments of a few
+// thousand candidates, where a batch is reached by two or three tiles and half the waves would
+// idle -- four batches, one per wave.
 template <int MODE>
 __global__ __launch_bounds__(kGraphThreads) __attribute__((amdgpu_waves_per_eu(kGraphPairWaves)))
 void k_graph_pairs(GraphArgs a, const int *ctrl)
 {
     __shared__ GraphWaveShared s_ws[kGraphWaves];
     __shared__ GraphSeg s_gs;
-    __shared__ int s_k[kGraphListCache];
+    __shared__ int s_pedge[kGraphWaves][64][kGraphEdges];   // suppressors of a lane's column during a walk
+    __shared__ int s_k[kGraphListCache];        // sizes of the segments of the current chunk of the list
+    __shared__ int s_mine[kGraphListCache];     // those this workgroup has groups of: index << 16 | first group
+    __shared__ int s_wsum[kGraphWaves];
+    __shared__ int s_nmine;
+    static_assert(kGraphListCache == 2 * kGraphThreads, "two segments per thread");
+    static_assert(kGraphPairGrid < 65536, "a workgroup number fits 16 bits");
     const int n_graph = ctrl[1];                    // graph segments of this launch
     if (n_graph == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const YpThr thr = yp_make_thr(a.thr);
     GraphWaveShared &ws = s_ws[wave];
-    // A batch of a segment of a few thousand candidates is reached by two or three tiles of rows:
-    // shared by the four waves of a workgroup, half of them would idle.  There every wave takes a
-    // batch of its own (and the window set-up is paid once per batch), provided the launch has
-    // batches to spare; the batches of larger segments, and of launches with few of them, are
-    // shared by the waves of a workgroup.  ctrl[2] counts the launch's candidates in units of 64.
-    // (Measured per 32 images at 1920x1280: 2 000 candidates per segment 324 -> 232 us with a batch
-    // per wave; 29 500 per segment 4.57 ms shared, 5.12 ms with a batch per wave.)
+#ifdef YP_STAMPS
+    // (diagnostic build: wall-clock ticks per workgroup -- start, list built, end -- and its groups)
+    unsigned long long *wg_dbg = a.dbg ? a.dbg + 32 + 4 * (size_t)blockIdx.x : nullptr;
+    if (threadIdx.x == 0 && wg_dbg) wg_dbg[0] = wall_clock64();
+    int dbg_groups = 0;
+    if (lane < 12) ws.dbg[lane] = 0u;
+#endif
+    // One batch per wave where the launch has batches to spare (ctrl[2] counts its candidates in
+    // units of 64).  (Measured per 32 images at 1920x1280: 2 000 candidates per segment 324 -> 232 us
+    // with a batch per wave; 29 500 per segment 4.57 ms shared, 5.12 ms with a batch per wave.)
     const bool spare = ctrl[2] * (64 / kGraphCols) >= 4 * (int)gridDim.x;
-    // (the segments' sizes once, in LDS: the loop below looks at every segment and takes part in
-    // few of them, and two dependent trips to memory per look would be most of its time)
-    const bool cached = n_graph <= kGraphListCache;
-    if (cached) {
-        for (int i = threadIdx.x; i < n_graph; i += kGraphThreads) s_k[i] = a.gseg[a.glist[i]].K;
-        __syncthreads();
-    }
-    for (int t = 0; t < n_graph; ++t) {
-        // nothing for this workgroup in this segment: on to the next (uniform, before any barrier)
-        const int K = __builtin_amdgcn_readfirstlane(cached ? s_k[t] : a.gseg[a.glist[t]].K);
-        const bool wave_mode = spare && K <= kGraphWaveModeMax;
-        const int per_wg = wave_mode ? kGraphWaves : 1;
-        const int n_batches = (K + kGraphCols - 1) / kGraphCols;
-        const int start = (int)((blockIdx.x + (unsigned)t * 37u) % gridDim.x);
-        if (start * per_wg >= n_batches) continue;
-        const int seg = a.glist[t];
-        __syncthreads();                            // everyone is done with the previous s_gs
-        {
-            const int *src = reinterpret_cast<const int *>(a.gseg + seg);
-            int *dst = reinterpret_cast<int *>(&s_gs);
-            for (int i = threadIdx.x; i < (int)(sizeof(GraphSeg) / 4); i += kGraphThreads) dst[i] = src[i];
+    // The groups of all segments are dealt to the workgroups round-robin as ONE sequence: segment
+    // t's group g goes to workgroup (groups of the segments before t + g) % grid, so every
+    // workgroup gets the same number of groups to within one.  A workgroup first works out, for 512
+    // segments of the list at a time and two per thread (a prefix sum over their group counts),
+    // which segments hold a group for it; its loop then only visits those -- two or three of the
+    // 160 segments of a launch of 2 000-candidate segments, where looking at every segment in turn
+    // cost more instructions than the pair tests.  (Handing the groups out from a counter instead,
+    // to whichever workgroup is free, evened out the workgroups' run times but made every workgroup
+    // work on the same segment at the same time: 3.97 -> 4.91 ms at 29 500 candidates per segment,
+    // 212 -> 205 us at 2 000.)
+    const unsigned int grid = gridDim.x;
+    unsigned int dealt = 0u;                        // groups of the chunks before this one, modulo the grid
+    for (int base = 0; base < n_graph; base += kGraphListCache) {
+        const int n_chunk = n_graph - base < kGraphListCache ? n_graph - base : kGraphListCache;
+        __syncthreads();                            // the lists of the chunk before are no longer read
+        if (threadIdx.x == 0) s_nmine = 0;
+        int ng[2], sum = 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = 2 * (int)threadIdx.x + u;
+            const int K = i < n_chunk ? a.gseg[a.glist[base + i]].K : 0;
+            const int n_batches = (K + kGraphCols - 1) / kGraphCols;
+            ng[u] = spare && K <= kGraphWaveModeMax ? (n_batches + kGraphWaves - 1) / kGraphWaves : n_batches;
+            sum += ng[u];
+            if (i < n_chunk) s_k[i] = K;
         }
+        const int incl = wave_inclusive_scan(sum, lane);
+        if (lane == 63) s_wsum[wave] = incl;
         __syncthreads();
-        const int b = a.per_class ? seg / a.C : seg;
-        const size_t reg = (size_t)b * a.spi + a.seg_region[seg];
-        const int *off = a.bin_tables + (size_t)s_gs.table * (kGraphBins + 1);
-        const float4 *xraw = a.xraw + reg;
-        const int *xidx = a.xidx + reg;
-        unsigned int pairs = 0, ties = 0;
-        for (int grp = start; grp * per_wg < n_batches; grp += gridDim.x) {
-            const int batch = wave_mode ? grp * kGraphWaves + wave : grp;
-            if (batch >= n_batches) continue;       // (uniform over the wave; nothing below is a workgroup barrier)
-            const int p = batch * kGraphCols + (lane & (kGraphCols - 1));
-            const bool live = p < K;
-            const float4 cj = xraw[live ? p : K - 1];
-            const int my_rank = live ? xidx[p] : -1;
-            bool kept_hit;
-            graph_walk<MODE, false>(s_gs, off, xraw, xidx, nullptr, a.gcnt + reg, a.gedge + reg * kGraphEdges,
-                                    cj, my_rank, p, live, thr, ws, wave_mode ? 0 : wave,
-                                    wave_mode ? 1 : kGraphWaves, nullptr, pairs, ties, kept_hit);
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kGraphWaves; ++w) {
+            woff += w < wave ? s_wsum[w] : 0;
+            total += s_wsum[w];
         }
-        if (lane == 0 && pairs) atomicAdd(&a.seg_pairs[seg], pairs);
-        if (lane == 0 && ties) atomicAdd(&a.seg_ties[seg], ties);
+        unsigned int before = dealt + (unsigned int)(woff + incl - sum);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = 2 * (int)threadIdx.x + u;
+            if (i < n_chunk) {
+                const unsigned int first = (blockIdx.x + grid - before % grid) % grid;
+                if (first < (unsigned int)ng[u]) s_mine[atomicAdd(&s_nmine, 1)] = (i << 16) | (int)first;
+            }
+            before += (unsigned int)ng[u];
+        }
+        dealt = (dealt + (unsigned int)total) % grid;
+        __syncthreads();
+        const int n_mine = s_nmine;
+#ifdef YP_STAMPS
+        if (threadIdx.x == 0 && wg_dbg && base == 0) wg_dbg[1] = wall_clock64();
+        dbg_groups += n_mine;
+#endif
+        for (int m = 0; m < n_mine; ++m) {
+            const int entry = __builtin_amdgcn_readfirstlane(s_mine[m]);
+            const int t = entry >> 16, start = entry & 0xffff;
+            const int K = __builtin_amdgcn_readfirstlane(s_k[t]);
+            const bool wave_mode = spare && K <= kGraphWaveModeMax;
+            const int per_wg = wave_mode ? kGraphWaves : 1;
+            const int n_batches = (K + kGraphCols - 1) / kGraphCols;
+            const int seg = a.glist[base + t];
+            __syncthreads();                            // everyone is done with the previous s_gs
+            {
+                const int *src = reinterpret_cast<const int *>(a.gseg + seg);
+                int *dst = reinterpret_cast<int *>(&s_gs);
+                for (int i = threadIdx.x; i < (int)(sizeof(GraphSeg) / 4); i += kGraphThreads) dst[i] = src[i];
+            }
+            __syncthreads();
+            const int b = a.per_class ? seg / a.C : seg;
+            const size_t reg = (size_t)b * a.spi + a.seg_region[seg];
+            const int *off = a.bin_tables + (size_t)s_gs.table * (kGraphBins + 1);
+            const float4 *xraw = a.xraw + reg;
+            const int *xidx = a.xidx + reg;
+            unsigned int pairs = 0, ties = 0;
+#ifdef YP_STAMPS
+            const unsigned int gw_seg0 = (unsigned int)__builtin_readcyclecounter();
+#endif
+            for (int grp = start; grp * per_wg < n_batches; grp += gridDim.x) {
+                const int batch = wave_mode ? grp * kGraphWaves + wave : grp;
+                if (batch >= n_batches) continue;       // (uniform over the wave; nothing below is a workgroup barrier)
+                const int p = batch * kGraphCols + (lane & (kGraphCols - 1));
+                const bool live = p < K;
+                const float4 cj = xraw[live ? p : K - 1];
+                const int my_rank = live ? xidx[p] : -1;
+                bool kept_hit;
+                graph_walk<MODE, false>(s_gs, off, xraw, xidx, nullptr, a.gcnt + reg, a.gedge + reg * kGraphEdges,
+                                        cj, my_rank, p, live, thr, ws, wave_mode ? 0 : wave,
+                                        wave_mode ? 1 : kGraphWaves, s_pedge[wave][lane], pairs, ties, kept_hit);
+            }
+#ifdef YP_STAMPS
+            if (lane == 0) ws.dbg[7] += (unsigned int)__builtin_readcyclecounter() - gw_seg0;   // the segment's batch loop, everything
+#endif
+            if (lane == 0 && pairs) atomicAdd(&a.seg_pairs[seg], pairs);
+            if (lane == 0 && ties) atomicAdd(&a.seg_ties[seg], ties);
+        }
     }
+#ifdef YP_STAMPS
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 12 && a.dbg && ws.dbg[lane]) atomicAdd(a.dbg + lane, (unsigned long long)ws.dbg[lane]);
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_dbg) {
+        wg_dbg[2] = wall_clock64();
+        wg_dbg[3] = (unsigned long long)dbg_groups;
+    }
+#endif
 }
 
 // Keep set of one graph segment from the recorded suppressors, then its kept rows in rank

@@ -63,13 +63,6 @@ static_assert(kImgHalves == 16, "strip index arithmetic");
 // 32-bit mask words of a class of `cap` candidates: sum over its strips of cap - 32 h
 constexpr int img_mask_words(int cap) { return kImgHalves * cap - 16 * kImgHalves * (kImgHalves - 1); }
 
-// two binary32 values that are added and multiplied together (one packed instruction on gfx950)
-#if defined(__clang__)
-typedef float yp_f2 __attribute__((ext_vector_type(2)));
-#else
-typedef float yp_f2 __attribute__((vector_size(8)));
-#endif
-
 // dst (one value per lane) takes the wave-uniform value val in lane l (a literal) and keeps the
 // rest.  (The CPU emulation the tests run these kernels under defines the macro itself.)
 #ifndef YP_WRITELANE
@@ -98,59 +91,6 @@ __device__ __forceinline__ u64 wave_inclusive_scan64(u64 v, int lane)
         if (lane >= off) v += t;
     }
     return v;
-}
-
-// Two columns a, b (uniform over the wave) against one row per lane.  was / wbs: bit l set when
-// lane l's row suppresses the column.  The arithmetic is yp_suppress_pretest's for boxes whose
-// union is known to be positive (x2 >= x1, y2 >= y1, finite areas: checked when the boxes were
-// loaded) and a threshold inside the guard-band range; rows in ca_rows / cb_rows whose quotient
-// the bands leave undecided take the exact divide-and-compare and are counted as ties.
-template <int MODE>
-__device__ __forceinline__ void img_pair2(const float4 &ri, float ai, const float4 &ca,
-                                          const float4 &cb, float aa, float ab, const YpThr &thr,
-                                          u64 ca_rows, u64 cb_rows, u64 &was, u64 &wbs,
-                                          unsigned int &ties)
-{
-    const float plus1 = MODE == YP_MODE_YOLOV3 ? 1.0f : 0.0f;
-    const yp_f2 lo0 = {vmax(ri.x, ca.x), vmax(ri.x, cb.x)};
-    const yp_f2 lo1 = {vmax(ri.y, ca.y), vmax(ri.y, cb.y)};
-    const yp_f2 hi0 = {vmin(ri.z, ca.z), vmin(ri.z, cb.z)};
-    const yp_f2 hi1 = {vmin(ri.w, ca.w), vmin(ri.w, cb.w)};
-    yp_f2 d0 = hi0 - lo0;
-    yp_f2 d1 = hi1 - lo1;
-    d0 = d0 + plus1;
-    d1 = d1 + plus1;
-    d0[0] = vmax(d0[0], 0.0f);
-    d0[1] = vmax(d0[1], 0.0f);
-    d1[0] = vmax(d1[0], 0.0f);
-    d1[1] = vmax(d1[1], 0.0f);
-    const yp_f2 inter = d0 * d1;
-    const yp_f2 aj = {aa, ab};
-    yp_f2 uni = ai + aj;
-    uni = uni - inter;
-    const yp_f2 t_hi = uni * thr.hi;
-    const yp_f2 t_lo = uni * thr.lo;
-    u64 ya = __ballot(inter[0] > t_hi[0]);
-    u64 yb = __ballot(inter[1] > t_hi[1]);
-    const u64 na = __ballot(inter[0] < t_lo[0]);
-    const u64 nb = __ballot(inter[1] < t_lo[1]);
-    const u64 ua = ~(ya | na) & ca_rows;
-    const u64 ub = ~(yb | nb) & cb_rows;
-    if ((ua | ub) != 0ull) {   // rare: some quotient sits within 2^-20 of the threshold
-        const int lane = threadIdx.x & 63;
-        const YpPrep pi = {ri.x, ri.y, ri.z, ri.w, ai};
-        const YpPrep pa = {ca.x, ca.y, ca.z, ca.w, aa};
-        const YpPrep pb = {cb.x, cb.y, cb.z, cb.w, ab};
-        const bool ea = ((ua >> lane) & 1ull) && yp_suppresses_exact<MODE>(pi, pa, thr.thr);
-        const bool eb = ((ub >> lane) & 1ull) && yp_suppresses_exact<MODE>(pi, pb, thr.thr);
-        const u64 xa = __ballot(ea);
-        const u64 xb = __ballot(eb);
-        ya = (ya & ~ua) | xa;
-        yb = (yb & ~ub) | xb;
-        ties += (unsigned int)(__popcll(ua) + __popcll(ub));
-    }
-    was = ya & ca_rows;
-    wbs = yb & cb_rows;
 }
 
 template <int MODE, int NT, int CAP, int POOL>
@@ -444,14 +384,14 @@ void k_image_nms(SegArgs s)
                             const u64 rv = (u64)rows_valid | ((u64)rows_valid << 32);
 #pragma unroll
                             for (int q = 0; q < 4; q += 2)
-                                img_pair2<MODE>(ri, ai, col[q], col[q + 1], car[q], car[q + 1], thr, rv, rv,
+                                pair2_words<MODE>(ri, ai, col[q], col[q + 1], car[q], car[q + 1], thr, rv, rv,
                                                 word[q], word[q + 1], ties);
                         } else {
 #pragma unroll
                             for (int q = 0; q < 4; q += 2) {
                                 const u64 ra = (u64)rows_before(jr + q) | ((u64)rows_before(jr + 4 + q) << 32);
                                 const u64 rb = (u64)rows_before(jr + q + 1) | ((u64)rows_before(jr + 5 + q) << 32);
-                                img_pair2<MODE>(ri, ai, col[q], col[q + 1], car[q], car[q + 1], thr, ra, rb,
+                                pair2_words<MODE>(ri, ai, col[q], col[q + 1], car[q], car[q + 1], thr, ra, rb,
                                                 word[q], word[q + 1], ties);
                             }
                         }

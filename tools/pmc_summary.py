@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc counter_collection CSVs: per kernel, the mean counter value
-per launch.  Usage: python tools/pmc_summary.py <dir-or-csv> [...]"""
+per launch -- over all launches, and over the launches of the kernel's largest grid alone (a
+bench run also holds single-batch launches of the same kernels: its pilot and latency passes).
+Usage: python tools/pmc_summary.py <dir-or-csv> [...]"""
 import collections
 import csv
 import glob
@@ -14,16 +16,22 @@ def summarise(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in files:
         per_dispatch = collections.defaultdict(float)
-        names = {}
+        names, grids = {}, {}
         for r in csv.DictReader(open(f)):
             key = (r["Dispatch_Id"], r["Counter_Name"])
             per_dispatch[key] += float(r["Counter_Value"])
             names[r["Dispatch_Id"]] = r["Kernel_Name"]
+            grids[r["Dispatch_Id"]] = int(r.get("Grid_Size") or 0)
         for (disp, ctr), v in per_dispatch.items():
-            acc[names[disp]][ctr].append(v)
+            acc[names[disp]][ctr].append((grids[disp], v))
     out = {}
     for k, ctrs in acc.items():
-        out[k] = {c: {"launches": len(v), "mean": sum(v) / len(v)} for c, v in ctrs.items()}
+        out[k] = {}
+        for c, gv in ctrs.items():
+            top = max(g for g, _ in gv)
+            big = [v for g, v in gv if g == top]
+            out[k][c] = {"launches": len(gv), "mean": sum(v for _, v in gv) / len(gv), "largest_grid": top,
+                         "launches_largest_grid": len(big), "mean_largest_grid": sum(big) / len(big)}
     return out
 
 

@@ -9,14 +9,15 @@ import sys
 src, cfg, sets, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 s = json.load(open(src))
 name = [k for k in s if "k_front_heads_v3" in k][0]
-fetch, write = s[name]["FETCH_SIZE"]["mean"], s[name]["WRITE_SIZE"]["mean"]
+# (the launches of the largest grid: the bench's launches of `sets` batches, not its single-batch passes)
+fetch, write = s[name]["FETCH_SIZE"]["mean_largest_grid"], s[name]["WRITE_SIZE"]["mean_largest_grid"]
 try:
     out = json.load(open(dst))
 except (OSError, ValueError):
     out = {}
 out[cfg] = {
     "kernel": re.search(r"k_front_heads_v3\w*(<[^>]*>)?", name).group(0), "sets_per_launch": sets,
-    "launches_averaged": s[name]["FETCH_SIZE"]["launches"],
+    "launches_averaged": s[name]["FETCH_SIZE"]["launches_largest_grid"],
     "FETCH_SIZE_KiB_raw": round(fetch, 1), "WRITE_SIZE_KiB": round(write, 1),
     "fetch_bytes_corrected": int(2 * fetch * 1024), "write_bytes": int(write * 1024),
     "traffic_bytes": int(2 * fetch * 1024 + write * 1024),
