@@ -41,8 +41,8 @@ constexpr int kFrontCells = 64 * kFrontGroups;
 constexpr int kStageWin = 128;    // survivors staged per round by the single-wave front kernel
 constexpr int kSegThreads = 512;  // threads per NMS workgroup (the kernel is only validated for 512)
 constexpr int kSegWaves = kSegThreads / 64;
-constexpr int kSortCap = 2048;    // largest segment whose keys are gathered straight into LDS
-constexpr int kBigSortCap = 4096; // largest segment sorted in LDS (gathered to memory first)
+constexpr int kSortCap = 2048;    // keys the first part of the sort block (s_raw) holds
+constexpr int kBigSortCap = 4096; // largest segment gathered into and sorted in LDS (the whole block)
 constexpr int kSmallCap = 512;    // segments up to this size use the all-pairs LDS bitmask path
 constexpr int kSmallWords = kSmallCap / 64;
 // words of the triangular pairwise bitmask of a kSmallCap segment: sum_w (cap - 64 w)
@@ -50,7 +50,7 @@ constexpr int kMaskWords = kSmallWords * kSmallCap - 32 * kSmallWords * (kSmallW
 constexpr int kRawBytes = (kSortCap * 8 > kMaskWords * 8) ? kSortCap * 8 : kMaskWords * 8;
 constexpr int kSmallBytes = 32 * (kSmallCap + 8) + 16 * 32;   // + 32 boxes the pair loop may over-read
 constexpr int kGraphMinCand = 768;      // segments with more candidates can take the graph path
-constexpr int kGraphPairGrid = 1280;    // workgroups of k_graph_pairs at most
+constexpr int kGraphPairGrid = 1024;    // workgroups of k_graph_pairs at most: what is resident at 4 waves per SIMD
 struct GraphSeg;
 
 // ------------------------------------------------------------------------ device structs
@@ -115,7 +115,7 @@ struct SegArgs {
     const int *cand_cls;
     const int *tile_count;
     int *tile_prefix;        // [B*tpi] exclusive prefix of tile_count inside an image
-    u64 *gkeys;              // [2*B*spi] sort area for segments larger than kSortCap, then their
+    u64 *gkeys;              // [2*B*spi] sort area for segments larger than kBigSortCap, then their
                              // boxes in x order
     float4 *sbox;            // [B*spi] boxes in sorted order, per segment region
     int *sslot;              // [B*spi] slot ids in sorted order
@@ -1399,9 +1399,9 @@ template <int MODE>
 __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vblk, const int nblk)
 {
     [[maybe_unused]] const int stamp_block = vblk;   // (diagnostic builds)
-    // s_raw: sort keys of segments above kSmallCap (bitonic sort, up to kSortCap keys); for
+    // s_raw: sort keys of segments above kSmallCap (bitonic sort; up to kBigSortCap keys run on into s_small); for
     // small segments the triangular pairwise suppression bitmask.
-    // s_small: [0, 8(cap+8)) gathered keys, later the sorted slot ids and box areas;
+    // s_small: [0, 8(cap+8)) the sorted slot ids and box areas;
     // [8(cap+8), 16(cap+8)) sorted keys; [16(cap+8), 32(cap+8)) the sorted boxes.
     // (one block, so that a segment of up to kBigSortCap keys can be sorted across both parts)
     __shared__ __align__(16) unsigned char s_lds[kRawBytes + kSmallBytes];
@@ -1466,86 +1466,88 @@ __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vbl
     // one trip to memory; slots past the count hold stale values that are ignored), keeps the
     // candidates of this segment and appends their sort keys in any order
     u64 *keys_in = reinterpret_cast<u64 *>(s_raw);
-    u64 *keys_small = reinterpret_cast<u64 *>(s_small);
+    // (the copy the small-segment path sorts from lives in the chunk loop's scratch, which nothing
+    // else uses before that sort is done: the gather may then fill the WHOLE sort block, and a
+    // segment of up to kBigSortCap candidates is gathered once)
+    u64 *keys_small = reinterpret_cast<u64 *>(&s_chunk);
+    static_assert(sizeof(ChunkShared) >= (kSmallCap + 8) * sizeof(u64), "the small path's keys fit");
     u64 *gk = s.gkeys + 2 * ibase;  // rebased to the segment's region below
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     auto gather = [&](bool to_lds, u64 *gdst) {
         int lt = 0;
         constexpr int kGatherTiles = 4;
-        auto take = [&](int slot, bool valid, float kf, int cl) {
-            const bool below = valid && cl < c;
-            const bool mine = valid && cl == c;
-            const u64 key = ((u64)(~yp_float_order_bits(kf)) << 32) | (u64)(unsigned int)slot;
-            lt += __popcll(__ballot(below));   // wave-uniform count
-            const u64 m = __ballot(mine);
-            if (m != 0ull) {
+        // kGatherTiles x 64 candidates whose key and class were requested together: those of this
+        // segment get consecutive output positions from one reservation
+        auto place = [&](const int (&slot)[kGatherTiles], const bool (&valid)[kGatherTiles],
+                         const float (&kf)[kGatherTiles], const int (&cl)[kGatherTiles]) {
+            u64 m[kGatherTiles];
+            int total = 0;
+#pragma unroll
+            for (int u = 0; u < kGatherTiles; ++u) {
+                lt += __popcll(__ballot(valid[u] && cl[u] < c));   // wave-uniform count
+                m[u] = __ballot(valid[u] && cl[u] == c);
+                total += __popcll(m[u]);
+            }
+            if (total > 0) {
                 int basepos = 0;
-                if (lane == 0) basepos = atomicAdd(&s_cnt[1], __popcll(m));
+                if (lane == 0) basepos = atomicAdd(&s_cnt[1], total);
                 basepos = __shfl(basepos, 0, 64);
-                if (mine) {
-                    const int pos = basepos + __popcll(m & lanes_below(lane));
-                    if (to_lds) {
-                        if (pos < kSortCap) keys_in[pos] = key;
-                        if (pos < kSmallCap) keys_small[pos] = key;
-                    } else {
-                        gdst[pos] = key;
+#pragma unroll
+                for (int u = 0; u < kGatherTiles; ++u) {
+                    if ((m[u] >> lane) & 1ull) {
+                        const u64 key = ((u64)(~yp_float_order_bits(kf[u])) << 32) | (u64)(unsigned int)slot[u];
+                        const int pos = basepos + __popcll(m[u] & lanes_below(lane));
+                        if (to_lds) {
+                            if (pos < kBigSortCap) keys_in[pos] = key;
+                            if (pos < kSmallCap) keys_small[pos] = key;
+                        } else {
+                            gdst[pos] = key;
+                        }
                     }
+                    basepos += __popcll(m[u]);
                 }
             }
         };
         // (tiles are dealt to the waves round-robin, so a few tiles still spread over the waves)
         for (int t0 = wv; t0 < tpi; t0 += kSegWaves * kGatherTiles) {
-            int cnt[kGatherTiles], cl[kGatherTiles];
-            float kf[kGatherTiles];
-#pragma unroll
-            for (int u = 0; u < kGatherTiles; ++u) {
-                const int t = t0 + u * kSegWaves;
-                const int tile = t < tpi ? t : tpi - 1;
-                const int slot = tile * ts + lane;
-                cnt[u] = t < tpi ? tcount[tile] : 0;
-                kf[u] = s.cand_key[ibase + slot];
-                cl[u] = s.per_class ? s.cand_cls[ibase + slot] : c;
-            }
-            {   // the round's tiles share one reservation of output positions
-                u64 m[kGatherTiles];
-                int total = 0;
+            int cnt[kGatherTiles];
+            {
+                int slot[kGatherTiles], cl[kGatherTiles];
+                bool valid[kGatherTiles];
+                float kf[kGatherTiles];
 #pragma unroll
                 for (int u = 0; u < kGatherTiles; ++u) {
-                    const bool valid = lane < cnt[u];
-                    lt += __popcll(__ballot(valid && cl[u] < c));
-                    m[u] = __ballot(valid && cl[u] == c);
-                    total += __popcll(m[u]);
+                    const int t = t0 + u * kSegWaves;
+                    const int tile = t < tpi ? t : tpi - 1;
+                    slot[u] = tile * ts + lane;
+                    cnt[u] = t < tpi ? tcount[tile] : 0;
+                    kf[u] = s.cand_key[ibase + slot[u]];
+                    cl[u] = s.per_class ? s.cand_cls[ibase + slot[u]] : c;
                 }
-                if (total > 0) {
-                    int basepos = 0;
-                    if (lane == 0) basepos = atomicAdd(&s_cnt[1], total);
-                    basepos = __shfl(basepos, 0, 64);
 #pragma unroll
-                    for (int u = 0; u < kGatherTiles; ++u) {
-                        if ((m[u] >> lane) & 1ull) {
-                            const int slot = (t0 + u * kSegWaves) * ts + lane;
-                            const u64 key = ((u64)(~yp_float_order_bits(kf[u])) << 32) |
-                                            (u64)(unsigned int)slot;
-                            const int pos = basepos + __popcll(m[u] & lanes_below(lane));
-                            if (to_lds) {
-                                if (pos < kSortCap) keys_in[pos] = key;
-                                if (pos < kSmallCap) keys_small[pos] = key;
-                            } else {
-                                gdst[pos] = key;
-                            }
-                        }
-                        basepos += __popcll(m[u]);
-                    }
-                }
+                for (int u = 0; u < kGatherTiles; ++u) valid[u] = lane < cnt[u];
+                place(slot, valid, kf, cl);
             }
-            // tiles with more than 64 candidates (rare): the rest, 64 at a time
-#pragma unroll
+            // tiles with more than 64 candidates (low confidence thresholds, crowded scenes): the
+            // rest of each, again kGatherTiles x 64 candidates per trip to memory
+#pragma nounroll
             for (int u = 0; u < kGatherTiles; ++u) {
-                for (int r0 = 64; r0 < cnt[u]; r0 += 64) {
-                    const int r = r0 + lane;
-                    const int slot = (t0 + u * kSegWaves) * ts + (r < cnt[u] ? r : 0);
-                    take(slot, r < cnt[u], s.cand_key[ibase + slot],
-                         s.per_class ? s.cand_cls[ibase + slot] : c);
+                const int tbase = (t0 + u * kSegWaves) * ts;
+                const int cu = u == 0 ? cnt[0] : (u == 1 ? cnt[1] : (u == 2 ? cnt[2] : cnt[3]));
+                static_assert(kGatherTiles == 4, "the selection above");
+                for (int r0 = 64; r0 < cu; r0 += 64 * kGatherTiles) {
+                    int slot[kGatherTiles], cl[kGatherTiles];
+                    bool valid[kGatherTiles];
+                    float kf[kGatherTiles];
+#pragma unroll
+                    for (int v = 0; v < kGatherTiles; ++v) {
+                        const int r = r0 + 64 * v + lane;
+                        valid[v] = r < cu;
+                        slot[v] = tbase + (valid[v] ? r : 0);
+                        kf[v] = s.cand_key[ibase + slot[v]];
+                        cl[v] = s.per_class ? s.cand_cls[ibase + slot[v]] : c;
+                    }
+                    place(slot, valid, kf, cl);
                 }
             }
         }
@@ -1799,11 +1801,11 @@ __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vbl
         }
         sslot_final = lslot;
     } else {
-        // ---- large segment: bitonic sort (LDS up to kSortCap keys, else global), sorted
+        // ---- large segment: bitonic sort (LDS up to kBigSortCap keys, else global), sorted
         // boxes / flags / slots in the global workspace region of the segment
         int n_pad = 2;
         while (n_pad < K) n_pad <<= 1;
-        const bool in_lds = K <= kSortCap;
+        const bool in_lds = K <= kBigSortCap;
         u64 *gdst = gk + 2 * (size_t)region;
         if (!in_lds) {
             __syncthreads();
@@ -1817,23 +1819,17 @@ __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vbl
             else gdst[i] = ~0ull;
         }
         __syncthreads();
-        // keys gathered to memory still sort in LDS when they fit the whole block (the tile
-        // prefix and everything else in it is dead by now)
-        const bool big_lds = !in_lds && n_pad <= kBigSortCap;
         if (in_lds && n_pad == 2 * kSegThreads) bitonic_sort_wide<2>(keys_in, n_pad);
         else if (in_lds && n_pad == 4 * kSegThreads) bitonic_sort_wide<4>(keys_in, n_pad);
+        else if (in_lds && n_pad == 8 * kSegThreads) bitonic_sort_wide<8>(keys_in, n_pad);
         else if (in_lds) bitonic_sort(keys_in, n_pad);
-        else if (big_lds) {
-            for (int i = tid; i < n_pad; i += kSegThreads) keys_in[i] = gdst[i];
-            __syncthreads();
-            bitonic_sort(keys_in, n_pad);
-        } else bitonic_sort_blocked(gdst, keys_in, n_pad);
+        else bitonic_sort_blocked(gdst, keys_in, n_pad);
         STAMP(3);
         float4 *gbox = s.sbox + reg;
         int *gslot = s.sslot + reg;
         unsigned char *grem = s.removed + reg;
         for (int i = tid; i < K; i += kSegThreads) {
-            const int slot = (int)(unsigned int)((in_lds || big_lds ? keys_in[i] : gdst[i]) & 0xffffffffull);
+            const int slot = (int)(unsigned int)((in_lds ? keys_in[i] : gdst[i]) & 0xffffffffull);
             gslot[i] = slot;
             gbox[i] = s.cand_box[ibase + slot];
             grem[i] = 0;
@@ -2000,6 +1996,8 @@ __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vbl
                     s.seg_ties[seg] = 0u;
                     s.ctrl[0] = 1;
                 }
+                STAMP(5);   // (diagnostic build: the index build shows as the NMS phase)
+                STAMP(6);
                 return;
             }
             __syncthreads();   // not eligible: the scratch goes back to the chunked path below
