@@ -575,6 +575,12 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
             const bool wave_mode = spare && K <= kGraphWaveModeMax;
             const int per_wg = wave_mode ? kGraphWaves : 1;
             const int n_batches = (K + kGraphCols - 1) / kGraphCols;
+            const int n_groups = (n_batches + per_wg - 1) / per_wg;
+            // Where a group sits in its segment's index decides what it costs (the index is ordered by
+            // size class, and small boxes look at all the larger ones), and with segments of equal
+            // size the deal above gives a workgroup the same place in every segment it visits: the
+            // groups of a segment are therefore taken in an order rotated by a per-segment amount.
+            const int rot = (int)((((unsigned int)(base + t) * 2654435761u) >> 8) % (unsigned int)n_groups);
             const int seg = a.glist[base + t];
             __syncthreads();                            // everyone is done with the previous s_gs
             {
@@ -592,7 +598,8 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
 #ifdef YP_STAMPS
             const unsigned int gw_seg0 = (unsigned int)__builtin_readcyclecounter();
 #endif
-            for (int grp = start; grp * per_wg < n_batches; grp += gridDim.x) {
+            for (int g0 = start; g0 < n_groups; g0 += gridDim.x) {
+                const int grp = g0 + rot < n_groups ? g0 + rot : g0 + rot - n_groups;
                 const int batch = wave_mode ? grp * kGraphWaves + wave : grp;
                 if (batch >= n_batches) continue;       // (uniform over the wave; nothing below is a workgroup barrier)
                 const int p = batch * kGraphCols + (lane & (kGraphCols - 1));
