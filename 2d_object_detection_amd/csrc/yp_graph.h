@@ -10,13 +10,13 @@
 //                   segment as before; for a large segment it then only builds a spatial index
 //                   -- the boxes binned by (size class, cell row, cell column) of their centre
 //                   with a counting sort -- and leaves.
-//   k_graph_pairs   many workgroups per segment.  A workgroup takes 64 boxes that are neighbours
-//                   in the index ("columns", one per lane), looks up the bins of their own and of
-//                   larger size classes whose boxes can overlap any of them, stages those "rows"
-//                   in LDS and tests every row against the 64 columns with the same staged,
-//                   division-free test as the other paths.  For every box it records (atomics)
-//                   how many earlier-ranked boxes suppress it, the earliest of them and up to
-//                   seven more.
+//   k_graph_pairs   many workgroups per segment.  A workgroup (or one of its waves) takes 32 boxes
+//                   that are neighbours in the index ("columns", each held by two lanes), looks up
+//                   the bins of their own and of larger size classes whose boxes can overlap any of
+//                   them, stages those "rows" in LDS and tests every row against the columns with
+//                   the division-free test of the other paths, two rows per packed instruction.
+//                   For every box it records (atomics) how many earlier-ranked boxes suppress it,
+//                   the earliest of them and up to seven more.
 //   k_graph_resolve one workgroup per segment iterates  "a suppressor is KEPT -> SUPPRESSED;
 //                   all suppressors SUPPRESSED -> KEPT"  over the undecided columns until none is
 //                   left (the lowest-ranked undecided column can always be decided, so at most
@@ -41,15 +41,18 @@ constexpr int kGraphEdges = 8;            // recorded suppressors per column (th
 // fewer rows reach it; the number of batches grows instead.  (Measured on an MI355X at 1920x1280:
 // 64 columns 4.89 ms per 32 images at 29 500 candidates per segment, 32 columns 4.49 ms, 16
 // columns 5.02 ms; 401 / 366 / 374 us at 2 000 candidates per segment.)
-// Candidate rows a wave fetches per pass, and the waves per SIMD k_graph_pairs is compiled for
-// (128 vector registers, no scratch).  Measured on an MI355X, pair kernel per 32 images at
-// 1920x1280: tiles of 256 rows at 3 waves per SIMD 4.47 ms / 368 us / 1.10 ms (29 500 candidates
-// per segment / 2 000 / clustered scenes), 128 rows at 4 waves 4.57 ms / 324 us / 0.95 ms, 64 rows
-// at 4 waves 4.80 ms / 309 us / 0.89 ms.
+// Candidate rows a wave fetches per trip to memory, and the waves per SIMD k_graph_pairs is
+// compiled for (128 vector registers, no scratch).  A wave has two tiles in registers: the one it
+// sifts and tests, and the next one, requested before that work starts.  (Measured on an MI355X
+// before the tiles were fetched ahead, pair kernel per 32 images at 1920x1280: tiles of 256 rows
+// at 3 waves per SIMD 4.47 ms / 368 us / 1.10 ms (29 500 candidates per segment / 2 000 /
+// clustered scenes), 128 rows at 4 waves 4.57 ms / 324 us / 0.95 ms, 64 rows at 4 waves 4.80 ms /
+// 309 us / 0.89 ms; with the next tile in flight 64-row tiles fit the register budget and gave
+// 4.21 ms / 185 us / 0.77 ms.)
 constexpr int kGraphRowTile = 64;
 constexpr int kGraphPairWaves = 4;
 constexpr int kGraphWaveModeMax = 8192;   // segments up to this size: one batch per wave of k_graph_pairs
-constexpr int kGraphListCache = 512;      // graph segments whose sizes k_graph_pairs keeps in LDS
+constexpr int kGraphListCache = 512;      // graph segments k_graph_pairs looks at per pass over the list
 constexpr int kGraphThreads = 256;        // k_graph_pairs workgroup
 constexpr int kGraphWaves = kGraphThreads / 64;
 constexpr int kGraphRanges = 64;          // bin ranges a wave looks up per pass
@@ -216,9 +219,9 @@ __device__ __forceinline__ void graph_record(int *gcnt, int *gedge, int target, 
 // Candidate rows are looked at by one lane each when they are fetched: a row that cannot touch
 // the batch's bounding box, whose class is out of order for the pair rule, or that is already
 // suppressed (REBUILD) is dropped there; the others are packed into LDS, and whenever enough
-// have gathered they are tested four at a time (uniform) against the 64 columns.  With COLS < 64
-// columns per batch (k_graph_pairs only) lane l holds column l % COLS and takes the rows
-// l / COLS, 64 / COLS + l / COLS, ... of every group of 4 * 64 / COLS rows.
+// have gathered they are tested against the columns, four per lane and step (two packed tests).
+// With COLS < 64 columns per batch (k_graph_pairs only) lane l holds column l % COLS and takes
+// the rows l / COLS, 64 / COLS + l / COLS, ... of every group of 4 * 64 / COLS rows.
 template <int MODE, bool REBUILD>
 __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, const float4 *xraw,
                                           const int *xidx, const unsigned char *status, int *gcnt,
@@ -253,7 +256,7 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
     const int c_hi = cB + gs.d < kGraphClasses - 1 ? cB + gs.d : kGraphClasses - 1;
 
     int n_buf = 0;      // useful rows waiting in LDS (uniform)
-    // test the waiting rows against the columns, four (uniform) rows at a time
+    // test the waiting rows against the columns, four rows per lane and step
     auto flush = [&]() {
         GW_T(4);
         GW_N(10, (n_buf + 4 * REP - 1) / (4 * REP));

@@ -48,3 +48,11 @@ for k, n in enumerate(names):
     d = t[:, k + 1] - t[:, k]
     print("%-8s mean %.2f us  max %.2f us" % (n, d.mean(), d.max()))
 print("workgroup total mean %.2f us max %.2f us" % ((t[:, 6] - t[:, 0]).mean(), (t[:, 6] - t[:, 0]).max()))
+tot = t[:, 6] - t[:, 0]
+print("workgroup total percentiles 50/90/99/max: %s us" % np.round(np.percentile(tot, [50, 90, 99, 100]), 2))
+for k, n in enumerate(names):
+    d = t[:, k + 1] - t[:, k]
+    print("  %-8s percentiles 50/90/99/max: %s us" % (n, np.round(np.percentile(d, [50, 90, 99, 100]), 2)))
+print("the five slowest workgroups (phases in us):")
+for i in np.argsort(-tot)[:5]:
+    print("  total %.2f: %s" % (tot[i], ", ".join("%s %.2f" % (n, t[i, k + 1] - t[i, k]) for k, n in enumerate(names))))
