@@ -56,7 +56,19 @@ if [ -f 2d_object_detection_amd/libyolopost_stamps.so ]; then
   YOLOPOST_LIB=$PWD/2d_object_detection_amd/libyolopost_stamps.so timeout -k 10 120 python3 tools/img_stamps.py > $OUT/image_nms_phase_stamps.txt 2>&1
   INP=608 YOLOPOST_LIB=$PWD/2d_object_detection_amd/libyolopost_stamps.so timeout -k 10 120 python3 tools/img_stamps.py >> $OUT/image_nms_phase_stamps.txt 2>&1
   cat $OUT/image_nms_phase_stamps.txt
+  # large segments: phases of the segment kernel (gather, sort, boxes, index build) and of the pair kernel's waves
+  : > $OUT/segment_nms_phase_stamps.txt
+  for c in 0.001 0.5; do
+    B=32 INP=1280,1920 CONF=$c YOLOPOST_LIB=$PWD/2d_object_detection_amd/libyolopost_stamps.so timeout -k 10 120 python3 tools/stamps.py 2>&1 | head -n 12 >> $OUT/segment_nms_phase_stamps.txt
+  done
+  : > $OUT/graph_pairs_phase_counters.txt
+  for c in "0.001 0" "0.5 0" "0.5 1"; do
+    set -- $c
+    CONF=$1 CLUSTERED=$2 YOLOPOST_LIB=$PWD/2d_object_detection_amd/libyolopost_stamps.so timeout -k 10 120 python3 tools/graph_stamps.py >> $OUT/graph_pairs_phase_counters.txt 2>&1
+  done
+  cat $OUT/graph_pairs_phase_counters.txt
 fi
+python3 tools/traffic_json.py $OUT/pmc_fetch_write.json cfg2 8 $OUT/front_kernel_traffic.json > /dev/null
 # the multi-rank code path (process group, barriers, all-gathers) with one rank on RCCL
 YP_BENCH_FORCE_DIST=1 YP_BENCH_WATCHDOG=120 timeout -k 10 200 python3 bench.py --no-cpu-baseline > $OUT/bench_rccl_world1.json 2> $OUT/bench_rccl_world1.err
 YP_BENCH_FORCE_DIST=1 YP_BENCH_WATCHDOG=120 timeout -k 10 200 python3 bench.py --no-cpu-baseline --exchange-every 4 > $OUT/bench_rccl_world1_exchange_every_4.json 2>> $OUT/bench_rccl_world1.err
