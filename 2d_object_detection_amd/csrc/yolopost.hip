@@ -1940,6 +1940,16 @@ __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vbl
                         base += g.nx[c] * g.ny[c];
                     }
                     g.n_bins = base;
+                    int pos = 0, nb = 0;
+                    for (int c = 0; c < kGraphClasses; ++c) {
+                        g.cpos[c] = pos;
+                        g.cbat[c] = nb;
+                        pos += s_cur[c];
+                        nb += (s_cur[c] + kGraphCols - 1) / kGraphCols;
+                    }
+                    g.cpos[kGraphClasses] = pos;
+                    g.cbat[kGraphClasses] = nb;
+                    g.n_batches = nb;
                     *s_g = g;
                 }
                 __syncthreads();

@@ -72,6 +72,12 @@ struct GraphSeg {
     float invy[kGraphClasses];
     float half[kGraphClasses];     // upper bound of half the box size in the class
     int nx[kGraphClasses], ny[kGraphClasses], base[kGraphClasses];
+    // Batches of k_graph_pairs never hold boxes of two size classes (the last boxes of one class's
+    // grid and the first of the next lie at opposite ends of the plane, and a batch of both would
+    // have to look at nearly every row): class c owns the index positions [cpos[c], cpos[c + 1])
+    // and the batches [cbat[c], cbat[c + 1]), the last of which may be partly filled.
+    int n_batches;
+    int cpos[kGraphClasses + 1], cbat[kGraphClasses + 1];
 };
 
 struct GraphArgs {
@@ -539,8 +545,11 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = 2 * (int)threadIdx.x + u;
-            const int K = i < n_chunk ? a.gseg[a.glist[base + i]].K : 0;
-            const int n_batches = (K + kGraphCols - 1) / kGraphCols;
+            // (a 32-bit byte offset from the uniform base: the address needs no 64-bit vector arithmetic)
+            const unsigned int goff = (unsigned int)a.glist[i < n_chunk ? base + i : base] * (unsigned int)sizeof(GraphSeg);
+            const char *gp = reinterpret_cast<const char *>(a.gseg) + goff;
+            const int K = i < n_chunk ? *reinterpret_cast<const int *>(gp + offsetof(GraphSeg, K)) : 0;
+            const int n_batches = i < n_chunk ? *reinterpret_cast<const int *>(gp + offsetof(GraphSeg, n_batches)) : 0;
             ng[u] = spare && K <= kGraphWaveModeMax ? (n_batches + kGraphWaves - 1) / kGraphWaves : n_batches;
             sum += ng[u];
             if (i < n_chunk) s_k[i] = K;
@@ -577,13 +586,6 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
             const int K = __builtin_amdgcn_readfirstlane(s_k[t]);
             const bool wave_mode = spare && K <= kGraphWaveModeMax;
             const int per_wg = wave_mode ? kGraphWaves : 1;
-            const int n_batches = (K + kGraphCols - 1) / kGraphCols;
-            const int n_groups = (n_batches + per_wg - 1) / per_wg;
-            // Where a group sits in its segment's index decides what it costs (the index is ordered by
-            // size class, and small boxes look at all the larger ones), and with segments of equal
-            // size the deal above gives a workgroup the same place in every segment it visits: the
-            // groups of a segment are therefore taken in an order rotated by a per-segment amount.
-            const int rot = (int)((((unsigned int)(base + t) * 2654435761u) >> 8) % (unsigned int)n_groups);
             const int seg = a.glist[base + t];
             __syncthreads();                            // everyone is done with the previous s_gs
             {
@@ -592,6 +594,13 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
                 for (int i = threadIdx.x; i < (int)(sizeof(GraphSeg) / 4); i += kGraphThreads) dst[i] = src[i];
             }
             __syncthreads();
+            const int n_batches = s_gs.n_batches;
+            const int n_groups = (n_batches + per_wg - 1) / per_wg;
+            // Where a group sits in its segment's index decides what it costs (the index is ordered by
+            // size class, and small boxes look at all the larger ones), and with segments of equal
+            // size the deal above gives a workgroup the same place in every segment it visits: the
+            // groups of a segment are therefore taken in an order rotated by a per-segment amount.
+            const int rot = (int)((((unsigned int)(base + t) * 2654435761u) >> 8) % (unsigned int)n_groups);
             const int b = a.per_class ? seg / a.C : seg;
             const size_t reg = (size_t)b * a.spi + a.seg_region[seg];
             const int *off = a.bin_tables + (size_t)s_gs.table * (kGraphBins + 1);
@@ -605,9 +614,11 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
                 const int grp = g0 + rot < n_groups ? g0 + rot : g0 + rot - n_groups;
                 const int batch = wave_mode ? grp * kGraphWaves + wave : grp;
                 if (batch >= n_batches) continue;       // (uniform over the wave; nothing below is a workgroup barrier)
-                const int p = batch * kGraphCols + (lane & (kGraphCols - 1));
-                const bool live = p < K;
-                const float4 cj = xraw[live ? p : K - 1];
+                int bc = 0;                             // the size class that owns the batch
+                while (bc + 1 < kGraphClasses && s_gs.cbat[bc + 1] <= batch) ++bc;
+                const int p = s_gs.cpos[bc] + (batch - s_gs.cbat[bc]) * kGraphCols + (lane & (kGraphCols - 1));
+                const bool live = p < s_gs.cpos[bc + 1];
+                const float4 cj = xraw[live ? p : s_gs.cpos[bc]];
                 const int my_rank = live ? xidx[p] : -1;
                 bool kept_hit;
                 graph_walk<MODE, false>(s_gs, off, xraw, xidx, nullptr, a.gcnt + reg, a.gedge + reg * kGraphEdges,
