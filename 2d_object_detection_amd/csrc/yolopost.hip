@@ -1941,11 +1941,12 @@ __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vbl
                     }
                     g.n_bins = base;
                     int pos = 0, nb = 0;
+                    g.cols = graph_cols(K);
                     for (int c = 0; c < kGraphClasses; ++c) {
                         g.cpos[c] = pos;
                         g.cbat[c] = nb;
                         pos += s_cur[c];
-                        nb += (s_cur[c] + kGraphCols - 1) / kGraphCols;
+                        nb += (s_cur[c] + g.cols - 1) / g.cols;
                     }
                     g.cpos[kGraphClasses] = pos;
                     g.cbat[kGraphClasses] = nb;
@@ -2600,8 +2601,8 @@ struct ProfileState {
                                      // graph pairs, graph resolve)
     unsigned char *launched = nullptr;  // per call: bit k set when kernel k was launched
 };
-constexpr int kProfKernels = 6, kProfEvents = 2 * kProfKernels;   // (the last one is k_image_nms)
-constexpr int kProfReported = 5;   // yp_profile_stop_ex: k_image_nms is added to the segment NMS time
+constexpr int kProfKernels = 7, kProfEvents = 2 * kProfKernels;   // ([5] k_image_nms, [6] the second k_graph_pairs)
+constexpr int kProfReported = 5;   // yp_profile_stop_ex: k_image_nms is added to the segment NMS time, the two pair kernels are one
 ProfileState g_prof;
 
 inline bool prof_active() { return g_prof.on && g_prof.calls < g_prof.max_calls; }
@@ -2703,8 +2704,13 @@ int finish_v3(const Workspace &w, const YpParams *p, int n_sets, int spi, int tp
         n_tables = n_tables < n_seg ? n_tables : n_seg;
         long long n_wg = slots_all / 64 / 2 + 1;
         n_wg = n_wg > kGraphPairGrid ? kGraphPairGrid : n_wg;
-        YP_LAUNCH(3, k_graph_pairs<YP_MODE_YOLOV3>, dim3((unsigned)n_wg), dim3(kGraphThreads), 0, st, ga,
-                  w.ctrl);
+        // (one launch per batch width: segments of fewer than kGraphWideMin candidates, then the larger
+        // ones; a launch without segments of its kind ends after a look at the list)
+        YP_LAUNCH(3, (k_graph_pairs<YP_MODE_YOLOV3, kGraphColsSmall>), dim3((unsigned)n_wg), dim3(kGraphThreads), 0,
+                  st, ga, w.ctrl);
+        if (spi >= kGraphWideMin)
+            YP_LAUNCH(6, (k_graph_pairs<YP_MODE_YOLOV3, 64>), dim3((unsigned)n_wg), dim3(kGraphThreads), 0, st, ga,
+                      w.ctrl);
         YP_LAUNCH(4, k_graph_resolve<YP_MODE_YOLOV3>, dim3((unsigned)n_tables), dim3(kSegThreads), 0, st, ga,
                   w.ctrl);
     }
@@ -3197,6 +3203,7 @@ int yp_profile_stop_ex(double *ms, int *calls)
     *calls = g_prof.calls;
     // averages per CALL (a kernel a call did not launch counts as zero time)
     acc[1] += acc[5];
+    acc[3] += acc[6];
     for (int k = 0; k < kProfReported; ++k) ms[k] = g_prof.calls ? acc[k] / g_prof.calls : 0.0;
     for (int i = 0; i < kProfEvents * g_prof.max_calls; ++i) (void)hipEventDestroy(g_prof.ev[i]);
     delete[] g_prof.ev;

@@ -36,11 +36,12 @@ constexpr int kGraphMin = kGraphMinCand;  // segments with more candidates take 
 constexpr int kGraphBins = 4096;          // bins of a segment's index (all classes together)
 constexpr int kGraphClasses = 8;          // size classes (powers of two of max(width, height))
 constexpr int kGraphEdges = 8;            // recorded suppressors per column (the earliest + 7)
-// Columns of a k_graph_pairs batch: 32, every column held by two lanes that test it against
-// different rows at the same time.  A narrower batch covers a smaller patch of the plane, so
-// fewer rows reach it; the number of batches grows instead.  (Measured on an MI355X at 1920x1280:
-// 64 columns 4.89 ms per 32 images at 29 500 candidates per segment, 32 columns 4.49 ms, 16
-// columns 5.02 ms; 401 / 366 / 374 us at 2 000 candidates per segment.)
+// Columns of a k_graph_pairs batch: with 32, every column is held by two lanes that test it
+// against different rows at the same time.  A narrower batch covers a smaller patch of the plane,
+// so fewer rows reach it; the number of batches, and with it the work of setting one up, grows
+// instead.  (Measured on an MI355X, pair kernel per 32 images at 1920x1280, batches of 16 / 32 /
+// 64 columns: 29 500 candidates per segment 2.98 / 2.55 / 2.24 ms, 2 000 per segment 95 / 95 /
+// 125 us, clustered scenes of 4 700 per segment 309 / 321 / 401 us.)
 // Candidate rows a wave fetches per trip to memory, and the waves per SIMD k_graph_pairs is
 // compiled for (128 vector registers, no scratch).  A wave has two tiles in registers: the one it
 // sifts and tests, and the next one, requested before that work starts.  (Measured on an MI355X
@@ -76,7 +77,7 @@ struct GraphSeg {
     // grid and the first of the next lie at opposite ends of the plane, and a batch of both would
     // have to look at nearly every row): class c owns the index positions [cpos[c], cpos[c + 1])
     // and the batches [cbat[c], cbat[c + 1]), the last of which may be partly filled.
-    int n_batches;
+    int n_batches, cols;        // (cols: columns per batch, graph_cols(K))
     int cpos[kGraphClasses + 1], cbat[kGraphClasses + 1];
 };
 
@@ -177,9 +178,12 @@ __device__ __forceinline__ int wave_max_i(int v)
 }
 
 constexpr int kGraphBuf = kGraphRowTile + 64;   // useful rows a wave collects before testing
-constexpr int kGraphCols = 32;
-static_assert(kGraphCols == 64 || kGraphCols == 32 || kGraphCols == 16, "columns per batch");
-static_assert(kGraphBuf % (4 * (64 / kGraphCols)) == 0, "padding of a flush stays inside the buffer");
+// Columns of a k_graph_pairs batch: 32 (each held by two lanes that take different rows of a step)
+// for segments of fewer than kGraphWideMin candidates, 64 for larger ones.
+constexpr int kGraphColsSmall = 32;
+constexpr int kGraphWideMin = 16384;
+static_assert(kGraphBuf % (4 * (64 / kGraphColsSmall)) == 0, "padding of a flush stays inside the buffer");
+__device__ __forceinline__ int graph_cols(int K) { return K >= kGraphWideMin ? 64 : kGraphColsSmall; }
 
 // Per-wave LDS of a walk.
 struct GraphWaveShared {
@@ -228,7 +232,7 @@ __device__ __forceinline__ void graph_record(int *gcnt, int *gedge, int target, 
 // have gathered they are tested against the columns, four per lane and step (two packed tests).
 // With COLS < 64 columns per batch (k_graph_pairs only) lane l holds column l % COLS and takes
 // the rows l / COLS, 64 / COLS + l / COLS, ... of every group of 4 * 64 / COLS rows.
-template <int MODE, bool REBUILD>
+template <int MODE, bool REBUILD, int COLS>
 __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, const float4 *xraw,
                                           const int *xidx, const unsigned char *status, int *gcnt,
                                           int *gedge, const float4 &cj, int my_rank, int my_pos,
@@ -241,7 +245,7 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
     GW_N(8, 1);
 #endif
     const int lane = threadIdx.x & 63;
-    constexpr int COLS = REBUILD ? 64 : kGraphCols, REP = 64 / COLS;
+    constexpr int REP = 64 / COLS;
     const int rslot = REP == 1 ? 0 : lane / COLS;     // which of the REP rows of a step this lane takes
     const YpBox bj = {cj.x, cj.y, cj.z, cj.w};
     const YpPrep pj = yp_prep<MODE>(bj);
@@ -496,10 +500,11 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
 // a segment whose row tiles the four waves of a workgroup share, or -- for segments of a few
 // thousand candidates, where a batch is reached by two or three tiles and half the waves would
 // idle -- four batches, one per wave.
-template <int MODE>
+template <int MODE, int COLS>
 __global__ __launch_bounds__(kGraphThreads) __attribute__((amdgpu_waves_per_eu(kGraphPairWaves)))
 void k_graph_pairs(GraphArgs a, const int *ctrl)
 {
+    static_assert(COLS == 64 || COLS == kGraphColsSmall, "the two batch widths");
     __shared__ GraphWaveShared s_ws[kGraphWaves];
     __shared__ GraphSeg s_gs;
     __shared__ int s_pedge[kGraphWaves][64][kGraphEdges];   // suppressors of a lane's column during a walk
@@ -524,7 +529,7 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
     // One batch per wave where the launch has batches to spare (ctrl[2] counts its candidates in
     // units of 64).  (Measured per 32 images at 1920x1280: 2 000 candidates per segment 324 -> 232 us
     // with a batch per wave; 29 500 per segment 4.57 ms shared, 5.12 ms with a batch per wave.)
-    const bool spare = ctrl[2] * (64 / kGraphCols) >= 4 * (int)gridDim.x;
+    const bool spare = ctrl[2] * (64 / kGraphColsSmall) >= 4 * (int)gridDim.x;
     // The groups of all segments are dealt to the workgroups round-robin as ONE sequence: segment
     // t's group g goes to workgroup (groups of the segments before t + g) % grid, so every
     // workgroup gets the same number of groups to within one.  A workgroup first works out, for 512
@@ -549,7 +554,8 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
             const unsigned int goff = (unsigned int)a.glist[i < n_chunk ? base + i : base] * (unsigned int)sizeof(GraphSeg);
             const char *gp = reinterpret_cast<const char *>(a.gseg) + goff;
             const int K = i < n_chunk ? *reinterpret_cast<const int *>(gp + offsetof(GraphSeg, K)) : 0;
-            const int n_batches = i < n_chunk ? *reinterpret_cast<const int *>(gp + offsetof(GraphSeg, n_batches)) : 0;
+            // (this instantiation takes the segments whose batches have COLS columns)
+            const int n_batches = i < n_chunk && graph_cols(K) == COLS ? *reinterpret_cast<const int *>(gp + offsetof(GraphSeg, n_batches)) : 0;
             ng[u] = spare && K <= kGraphWaveModeMax ? (n_batches + kGraphWaves - 1) / kGraphWaves : n_batches;
             sum += ng[u];
             if (i < n_chunk) s_k[i] = K;
@@ -616,12 +622,12 @@ void k_graph_pairs(GraphArgs a, const int *ctrl)
                 if (batch >= n_batches) continue;       // (uniform over the wave; nothing below is a workgroup barrier)
                 int bc = 0;                             // the size class that owns the batch
                 while (bc + 1 < kGraphClasses && s_gs.cbat[bc + 1] <= batch) ++bc;
-                const int p = s_gs.cpos[bc] + (batch - s_gs.cbat[bc]) * kGraphCols + (lane & (kGraphCols - 1));
+                const int p = s_gs.cpos[bc] + (batch - s_gs.cbat[bc]) * COLS + (lane & (COLS - 1));
                 const bool live = p < s_gs.cpos[bc + 1];
                 const float4 cj = xraw[live ? p : s_gs.cpos[bc]];
                 const int my_rank = live ? xidx[p] : -1;
                 bool kept_hit;
-                graph_walk<MODE, false>(s_gs, off, xraw, xidx, nullptr, a.gcnt + reg, a.gedge + reg * kGraphEdges,
+                graph_walk<MODE, false, COLS>(s_gs, off, xraw, xidx, nullptr, a.gcnt + reg, a.gedge + reg * kGraphEdges,
                                         cj, my_rank, p, live, thr, ws, wave_mode ? 0 : wave,
                                         wave_mode ? 1 : kGraphWaves, s_pedge[wave][lane], pairs, ties, kept_hit);
             }
@@ -746,7 +752,7 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
                 const float4 cj = xraw[in ? p : K - 1];
                 bool kept_hit;
                 int *le = s_edge[wave][lane];
-                const int cnt = graph_walk<MODE, true>(s_gs, off, xraw, xidx, status, nullptr, nullptr, cj,
+                const int cnt = graph_walk<MODE, true, 64>(s_gs, off, xraw, xidx, status, nullptr, nullptr, cj,
                                                        my_rank, p, need, thr, s_ws[wave], 0, 1, le, pairs,
                                                        ties, kept_hit);
                 if (need) {

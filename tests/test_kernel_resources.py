@@ -53,8 +53,8 @@ def test_check_refuses_a_build_that_leaves_the_table():
     tool = _tool()
     want = json.load(open(TABLE))
     worse = json.loads(json.dumps(want))
-    worse["k_graph_pairs<0>"]["scratch"] = 132
-    worse["k_graph_pairs<0>"]["occupancy"] = 5          # (more waves is not the problem ...)
+    worse["k_graph_pairs<0, 32>"]["scratch"] = 132
+    worse["k_graph_pairs<0, 32>"]["occupancy"] = 5          # (more waves is not the problem ...)
     worse["k_image_nms<0, 512, 1728, 4096>"]["lds"] += 4096
     worse["k_new_kernel"] = dict(want["k_bbox_iou"])
     bad = tool.check(worse, want)

@@ -125,8 +125,10 @@ def test_emulated_detect_matches_oracle(pkg, emu, nms_path, name, n_sets, B, inp
     emul_counters(emu)
     out, cnt, st = run_detect(pkg, emu, sets, inp_dim, conf, dense=dense, frame=frame, offset=3)
     c = emul_counters(emu)
-    # front, [per-image NMS,] per-segment NMS, row gather; the two graph kernels only with the flag
-    assert c["launches"] == (5 if dense else 3) + (nms_path == "image"), c
+    # front, [per-image NMS,] per-segment NMS, row gather; with the flag the pair kernel (a second time,
+    # for 64-column batches, when an image has room for a segment of 16 384 candidates) and the resolve kernel
+    slots_per_image = sum(-(-h.shape[2] * h.shape[3] // 128) * 128 * 3 for h in sets[0])
+    assert c["launches"] == 3 + (nms_path == "image") + ((2 + (slots_per_image >= 16384)) if dense else 0), c
     assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c      # every collective was wave-uniform
     for k, heads in enumerate(sets):
         want, surv, _ = oracle.n_detect(heads, inp_dim, syn.YOLOV3_ANCHORS, 5, conf, 0.4)
@@ -141,6 +143,22 @@ def test_emulated_detect_matches_oracle(pkg, emu, nms_path, name, n_sets, B, inp
             assert st[k, 0].max() > 768          # the case does exercise the large-segment code
         # rows beyond the count were never written
         assert (out[k, len(want):].view(np.uint8) == 0xA5).all()
+
+
+def test_emulated_graph_path_with_wide_batches(pkg, emu):
+    """A segment of more than 16 384 candidates (one class, one 640x960 image, nearly every anchor
+    kept by the confidence filter) takes the pair kernel's 64-column batches."""
+    syn = pkg.synthetic
+    inp_dim, conf, C = (640, 960), 0.001, 1
+    heads = [np.ascontiguousarray(h.numpy()) for h in syn.make_heads(1, inp_dim, C, seed=77)]
+    emul_counters(emu)
+    out, cnt, st = run_detect(pkg, emu, [heads], inp_dim, conf, C=C, dense=True)
+    c = emul_counters(emu)
+    assert c["launches"] == 6 and c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
+    want, surv, _ = oracle.n_detect(heads, inp_dim, syn.YOLOV3_ANCHORS, C, conf, 0.4)
+    assert st[0, 0].max() >= 16384
+    assert cnt[0] == len(want) and np.array_equal(out[0, :len(want)], want)
+    assert np.array_equal(st[0, 0].sum(1), surv) and st[0, 1].sum() == len(want)
 
 
 def test_ab_script_variants_are_valid_builds():
