@@ -688,6 +688,14 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
     // After its first round a round only visits the columns the round before left undecided (a
     // work list) instead of all of them: most columns are decided in the first two rounds.
     int *wl_a = a.work + reg * 4, *wl_b = wl_a + K;   // this round's / the next round's columns
+#ifdef YP_STAMPS
+    // (diagnostic build, thread 0: wall-clock ticks in the rounds' scans, the re-derivations and the
+    // output, and their numbers, summed over the segments into a.dbg[16..])
+    unsigned long long rs_t = wall_clock64(), rs_scan = 0, rs_redo = 0, rs_rounds = 0, rs_walks = 0;
+#define RS_T(acc) do { const unsigned long long n_ = wall_clock64(); acc += n_ - rs_t; rs_t = n_; } while (0)
+#else
+#define RS_T(acc) do { } while (0)
+#endif
 #define YP_WL_PUSH(p) (wl_b[atomicAdd(&s_nwork, 1)] = (p))
     int n_work = K;     // columns this round visits: all of them, or the work list's
     for (int round = 0; round < 2 * K + 2; ++round) {
@@ -733,6 +741,12 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
         if (undecided) atomicAdd(&s_undecided, undecided);
         if (redo) atomicAdd(&s_redo, redo);
         __syncthreads();
+#ifdef YP_STAMPS
+        ++rs_rounds;
+        if (tid == 0 && a.dbg && blockIdx.x == 0 && round < 10)   // (first segment: columns visited and ticks of the scan, per round)
+            a.dbg[22 + round] = ((wall_clock64() - rs_t) << 32) | (unsigned long long)n_work;
+#endif
+        RS_T(rs_scan);
         if (s_undecided == 0) break;
         {   // (read before thread 0 clears the counter at the top of the loop)
             n_work = s_nwork;
@@ -749,6 +763,9 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
                 const int my_rank = in ? xidx[p] : -1;
                 const bool need = in && gcnt[p] < 0 && status[my_rank] == kUndecided;
                 if (__ballot(need) == 0ull) continue;
+#ifdef YP_STAMPS
+                if (wave == 0) ++rs_walks;
+#endif
                 const float4 cj = xraw[in ? p : K - 1];
                 bool kept_hit;
                 int *le = s_edge[wave][lane];
@@ -766,6 +783,7 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
             }
         }
         __syncthreads();
+        RS_T(rs_redo);
     }
 #undef YP_WL_PUSH
     // kept rows in rank order
@@ -786,4 +804,17 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
     if (lane == 0 && pairs) atomicAdd(&a.seg_pairs[seg], pairs);
     if (lane == 0 && ties) atomicAdd(&a.seg_ties[seg], ties);
     if (tid == 0) a.seg_kept[seg] = nkept;
+#ifdef YP_STAMPS
+    if (tid == 0 && a.dbg) {
+        unsigned long long rs_emit = 0;
+        RS_T(rs_emit);
+        atomicAdd(a.dbg + 16, rs_rounds);
+        atomicAdd(a.dbg + 17, rs_walks);
+        atomicAdd(a.dbg + 18, rs_scan);
+        atomicAdd(a.dbg + 19, rs_redo);
+        atomicAdd(a.dbg + 20, rs_emit);
+        atomicAdd(a.dbg + 21, 1ull);
+    }
+#endif
+#undef RS_T
 }

@@ -65,3 +65,10 @@ for lo in range(0, int(st.max()) + 1, max(1, int(st.max() / 6) + 1)):
     sel = (st >= lo) & (st < lo + max(1, int(st.max() / 6) + 1))
     if sel.any():
         print("  started in [%d, %d) us: %4d workgroups, life mean %.1f max %.1f us, groups mean %.2f" % (lo, lo + max(1, int(st.max() / 6) + 1), sel.sum(), life[sel].mean(), life[sel].max(), w[sel, 3].mean()))
+
+r = dbg[nseg].cpu().numpy().astype("float64")[16:22]
+if r[5] > 0:
+    print("resolve kernel, per graph segment (%d of them): %.1f rounds, %.1f re-derivation walks of wave 0; wall time (10 ns ticks -> us) "
+          "scans %.1f, re-derivations %.1f, output %.1f us" % (r[5], r[0] / r[5], r[1] / r[5], r[2] / r[5] / 100, r[3] / r[5] / 100, r[4] / r[5] / 100))
+rr = dbg[nseg].cpu().numpy()[22:32]
+print("first graph segment, rounds (columns visited / scan time in us): " + ", ".join("%d / %.1f" % (int(v) & 0xffffffff, (int(v) >> 32) / 100.0) for v in rr if v))
