@@ -146,10 +146,10 @@ def test_emulated_detect_matches_oracle(pkg, emu, nms_path, name, n_sets, B, inp
 
 
 def test_emulated_graph_path_with_wide_batches(pkg, emu):
-    """A segment of more than 16 384 candidates (one class, one 640x960 image, nearly every anchor
+    """A segment of more than 16 384 candidates (one class, one 448x672 image, nearly every anchor
     kept by the confidence filter) takes the pair kernel's 64-column batches."""
     syn = pkg.synthetic
-    inp_dim, conf, C = (640, 960), 0.001, 1
+    inp_dim, conf, C = (448, 672), 0.001, 1
     heads = [np.ascontiguousarray(h.numpy()) for h in syn.make_heads(1, inp_dim, C, seed=77)]
     emul_counters(emu)
     out, cnt, st = run_detect(pkg, emu, [heads], inp_dim, conf, C=C, dense=True)
@@ -425,6 +425,12 @@ def test_emulated_kernels_under_address_and_ub_sanitizers(pkg, tmp_path):
         # workgroups) is replayed with the workgroups last to first and in a scrambled order as well
         for order in (("", "reverse", "shuffle") if name == "graph" else ("",)):
             replays.append((name + " " + order, [exe, path], dict(env, YP_EMUL_ORDER=order)))
+    # one segment of 18 000 candidates (a single class): the pair kernel's 64-column batches
+    wide = [np.ascontiguousarray(h.numpy()) for h in syn.make_heads(1, (448, 672), 1, seed=77)]
+    want, _, _ = oracle.n_detect(wide, (448, 672), syn.YOLOV3_ANCHORS, 1, 0.001, 0.4)
+    path = str(tmp_path / "wide.bin")
+    write_case(path, pkg, [wide], (448, 672), 0.001, 1, L.YP_FLAG_DENSE_NMS, len(want) + 2 & ~1, None, [want])
+    replays.append(("wide batches", [exe, path], dict(env, YP_EMUL_ORDER="reverse")))
     for label, out in replay_all(replays):
         assert out.returncode == 0, (label, out.stdout[-1500:], out.stderr[-3000:])
         assert out.stdout.strip().splitlines()[-1].startswith("ok"), (label, out.stdout[-500:])
