@@ -1901,6 +1901,8 @@ __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vbl
                     g.y0 = ylo;
                     g.margin = 2.0f + 4e-7f * (__builtin_fabsf(xlo) + __builtin_fabsf(xhi) +
                                                __builtin_fabsf(ylo) + __builtin_fabsf(yhi) + mhi);
+                    g.shrink = 0.9f * s.thr < 0.5f ? 0.9f * s.thr : 0.5f;
+                    g.cols = graph_cols(K);
                     const float xr = xhi - xlo, yr = yhi - ylo;
                     int base = 0;
                     for (int c = 0; c < kGraphClasses; ++c) {
@@ -1914,16 +1916,18 @@ __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vbl
                         // 2^(e_min + c + 1 - 127); the last class takes everything above its start
                         float ub = __uint_as_float((unsigned)(e_min + c + 1 < 254 ? e_min + c + 1 : 254) << 23);
                         if (c == kGraphClasses - 1) ub = vmax(ub, mhi * 1.0001f);
-                        g.half[c] = 0.5f * ub;
-                        // The class gets a share of the bins in proportion to its boxes.  64
-                        // consecutive index positions (one batch of columns) are a run of cells
-                        // along x, so the cells are made as tall as such a run is long -- about
-                        // sqrt(64 / density) -- and as narrow as the share allows: the batch then
+                        // (half the size of the largest core of the class, plus the half pixel between
+                        // a box's centre and the centre of the interval the IoU counts)
+                        g.half[c] = (1.0f - 2.0f * g.shrink) * 0.5f * ub + 1.0f;
+                        // The class gets a share of the bins in proportion to its boxes.  The
+                        // consecutive index positions of one batch of columns (32 or 64) are a run of
+                        // cells along x, so the cells are made as tall as such a run is long -- about
+                        // sqrt(columns / density) -- and as narrow as the share allows: the batch then
                         // covers a roughly square patch, which keeps its reach small.
                         const int budget = 8 + (int)((long long)(kGraphBins - 8 * kGraphClasses) * n_c / K);
                         int ny = 1;
                         if (yr > 0.0f && xr > 0.0f) {
-                            const float h = __builtin_sqrtf(64.0f * xr * (yr / (float)n_c));
+                            const float h = __builtin_sqrtf((float)g.cols * xr * (yr / (float)n_c));
                             const float fy = h > 0.0f ? yr / h : 1.0f;
                             ny = fy < 1.0f ? 1 : (fy > (float)budget ? budget : (int)fy);
                         } else if (yr > 0.0f) {
@@ -1941,7 +1945,6 @@ __device__ __forceinline__ void segment_nms_body(const SegArgs &s, const int vbl
                     }
                     g.n_bins = base;
                     int pos = 0, nb = 0;
-                    g.cols = graph_cols(K);
                     for (int c = 0; c < kGraphClasses; ++c) {
                         g.cpos[c] = pos;
                         g.cbat[c] = nb;

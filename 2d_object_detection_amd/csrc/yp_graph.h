@@ -24,12 +24,20 @@
 //                   from the index when the recorded ones are used up, and emits the kept rows in
 //                   rank order.
 //
-// Nothing is skipped that could change a verdict: a bin is left out only when every box in it
-// has zero intersection with every column of the batch (centres further apart than the half
-// sizes allow, with slack), or belongs to a size class whose boxes cannot reach the threshold
-// against the batch's classes (IoU <= min(w_i/w_j, h_i/h_j) for w_i <= w_j ...).  Both need a
-// positive threshold inside the guard-band range and boxes with positive width and height;
-// segments that do not qualify stay on the chunked path of k_segment_nms.
+// Nothing is skipped that could change a verdict.  A row r and a column c can only reach the
+// threshold if they overlap by a good part of the row: the union is at least the row's area and
+// the intersection is at most (overlap along x) * (the row's height), so IoU <= overlap_x / w_r and
+// likewise along y -- IoU >= thr needs an overlap of thr * w_r along x and thr * h_r along y (widths
+// and heights as the IoU counts them, the +1 included).  The column's box then reaches into the
+// row's CORE, the row's box with 0.9 * thr of its width and height (at most half) cut off on every
+// side; a pair whose column misses the core has IoU < 0.9 * thr, far outside any rounding of the
+// quotient.  So a row is dropped when its core misses the bounding box of the batch's columns, and
+// a bin is left out when no box of its class whose centre lies in it can have a core that reaches
+// that bounding box (with 2 px and the coordinates' rounding as slack), or when it belongs to a
+// size class whose boxes cannot reach the threshold against the batch's classes (IoU <=
+// min(w_i/w_j, h_i/h_j) for w_i <= w_j ...).  All of this needs a positive threshold inside the
+// guard-band range and boxes with ordered corners; segments that do not qualify stay on the
+// chunked path of k_segment_nms.
 #pragma once
 
 constexpr int kGraphMin = kGraphMinCand;  // segments with more candidates take this path
@@ -68,10 +76,12 @@ struct GraphSeg {
     int d;          // classes further apart than this cannot reach the threshold
     float x0, y0;   // smallest centre coordinates
     float margin;   // slack added to every reach (2 px + rounding of the coordinates)
+    float shrink;   // a row is looked at through its core: the box without this fraction of its width
+                    // and height on every side (see graph_walk)
     int n_bins;
     float invx[kGraphClasses];     // 1 / cell width and 1 / cell height of the class's grid
     float invy[kGraphClasses];
-    float half[kGraphClasses];     // upper bound of half the box size in the class
+    float half[kGraphClasses];     // upper bound of half the size of a box's CORE in the class
     int nx[kGraphClasses], ny[kGraphClasses], base[kGraphClasses];
     // Batches of k_graph_pairs never hold boxes of two size classes (the last boxes of one class's
     // grid and the first of the next lie at opposite ends of the plane, and a batch of both would
@@ -457,9 +467,11 @@ __device__ __forceinline__ int graph_walk(const GraphSeg &gs, const int *off, co
 #pragma unroll
             for (int k = 0; k < T; ++k) {
                 const int rc = graph_class(graph_box_size<MODE>(c4[k]), gs.e_min);
-                bool useful = k * 64 + lane < fill && !(c4[k].z + gs.margin < bxlo) &&
-                              !(c4[k].x - gs.margin > bxhi) && !(c4[k].w + gs.margin < bylo) &&
-                              !(c4[k].y - gs.margin > byhi);
+                // the row's core against the bounding box of the batch (see the note at the top)
+                const float sx = gs.shrink * (c4[k].z - c4[k].x + 1.0f), sy = gs.shrink * (c4[k].w - c4[k].y + 1.0f);
+                bool useful = k * 64 + lane < fill && !(c4[k].z + 1.0f - sx + gs.margin < bxlo) &&
+                              !(c4[k].x + sx - gs.margin > bxhi + 1.0f) && !(c4[k].w + 1.0f - sy + gs.margin < bylo) &&
+                              !(c4[k].y + sy - gs.margin > byhi + 1.0f);
                 if (!REBUILD) useful = useful && rc >= cA;
                 if (REBUILD && useful) useful = status[r4[k]] != kSuppressed;
                 const u64 m = __ballot(useful);
