@@ -52,6 +52,8 @@ DENSE=0 CONF=0.5 CLUSTERED=1 timeout -k 10 120 python3 tools/nms_breakdown.py >>
 cat $OUT/nms_breakdown.txt
 timeout -k 10 120 python3 tools/latency_sweep.py > $OUT/latency_sweep.txt 2>&1
 cat $OUT/latency_sweep.txt
+timeout -k 10 200 python3 tools/graph_latency.py > $OUT/latency_graph_replay.txt 2>&1
+cat $OUT/latency_graph_replay.txt
 if [ -f 2d_object_detection_amd/libyolopost_stamps.so ]; then
   YOLOPOST_LIB=$PWD/2d_object_detection_amd/libyolopost_stamps.so timeout -k 10 120 python3 tools/img_stamps.py > $OUT/image_nms_phase_stamps.txt 2>&1
   INP=608 YOLOPOST_LIB=$PWD/2d_object_detection_amd/libyolopost_stamps.so timeout -k 10 120 python3 tools/img_stamps.py >> $OUT/image_nms_phase_stamps.txt 2>&1
