@@ -670,6 +670,11 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
     __shared__ int s_edge[kSegWaves][64][kGraphEdges];
     __shared__ GraphSeg s_gs;
     __shared__ int s_undecided, s_redo;
+    // statuses of segments of up to kResolveLdsMax candidates, two bits each: a round reads the
+    // status of every column and of up to eight suppressors of it, one scattered byte each from
+    // memory otherwise (the global array is written all the same: the re-derivations read it)
+    constexpr int kResolveLdsMax = 32768;
+    __shared__ unsigned int s_st[kResolveLdsMax / 16];
     __shared__ int s_nwork;
     __shared__ u64 s_bal[kSegWaves];
     if ((int)blockIdx.x >= ctrl[1]) return;
@@ -682,6 +687,9 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
     __syncthreads();
     const int K = s_gs.K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool st_lds = K <= kResolveLdsMax;
+    for (int i = tid; i < kResolveLdsMax / 16; i += kSegThreads) s_st[i] = 0u;   // (kUndecided, as in memory)
+    static_assert(kUndecided == 0 && kKept == 1 && kSuppressed == 2, "two status bits, set once");
     const int b = a.per_class ? seg / a.C : seg;
     const size_t reg = (size_t)b * a.spi + a.seg_region[seg];
     const int *off = a.bin_tables + (size_t)s_gs.table * (kGraphBins + 1);
@@ -693,6 +701,14 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
     const YpThr thr = yp_make_thr(a.thr);
     unsigned int pairs = 0, ties = 0;
     const int n_batches = (K + 63) >> 6;
+    auto st_get = [&](int r) -> int {
+        return st_lds ? (int)((s_st[r >> 4] >> ((r & 15) * 2)) & 3u) : (int)status[r];
+    };
+    auto st_set = [&](int r, int v) {     // (a status goes from undecided to its final value once)
+        status[r] = (unsigned char)v;
+        if (st_lds) atomicOr(&s_st[r >> 4], (unsigned int)v << ((r & 15) * 2));
+    };
+    __syncthreads();
     // Rounds.  Statuses only ever go from undecided to their final value, so reading one that
     // another wave has just written is as good as reading it a round later.  Every round
     // decides at least the lowest-ranked undecided column (all its suppressors are decided), or
@@ -721,9 +737,9 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
         for (int q = tid; q < n_work; q += kSegThreads) {
             const int p = round > 0 ? wl_a[q] : q;
             const int r = xidx[p];
-            if (status[r] != kUndecided) continue;
+            if (st_get(r) != kUndecided) continue;
             const int cnt = gcnt[p];
-            if (cnt == 0) { status[r] = kKept; continue; }
+            if (cnt == 0) { st_set(r, kKept); continue; }
             if (cnt < 0) {                                        // list used up: re-derive below
                 ++redo; ++undecided;
                 YP_WL_PUSH(p);
@@ -737,13 +753,13 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
 #pragma unroll
             for (int k = 0; k < kGraphEdges; ++k) {
                 if (k <= listed) {       // [0] the earliest, [1..listed] the recorded ones
-                    const int st = status[e[k]];
+                    const int st = st_get(e[k]);
                     any_kept = any_kept || st == kKept;
                     all_sup = all_sup && st == kSuppressed;
                 }
             }
-            if (any_kept) status[r] = kSuppressed;
-            else if (all_sup && cnt <= kGraphEdges - 1) status[r] = kKept;
+            if (any_kept) st_set(r, kSuppressed);
+            else if (all_sup && cnt <= kGraphEdges - 1) st_set(r, kKept);
             else {
                 ++undecided;
                 if (all_sup) { gcnt[p] = -1; ++redo; }               // more suppressors than recorded
@@ -773,7 +789,7 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
                 const int p = batch * 64 + lane;
                 const bool in = p < K;
                 const int my_rank = in ? xidx[p] : -1;
-                const bool need = in && gcnt[p] < 0 && status[my_rank] == kUndecided;
+                const bool need = in && gcnt[p] < 0 && st_get(my_rank) == kUndecided;
                 if (__ballot(need) == 0ull) continue;
 #ifdef YP_STAMPS
                 if (wave == 0) ++rs_walks;
@@ -785,8 +801,8 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
                                                        my_rank, p, need, thr, s_ws[wave], 0, 1, le, pairs,
                                                        ties, kept_hit);
                 if (need) {
-                    if (kept_hit) status[my_rank] = kSuppressed;
-                    else if (cnt == 0) status[my_rank] = kKept;
+                    if (kept_hit) st_set(my_rank, kSuppressed);
+                    else if (cnt == 0) st_set(my_rank, kKept);
                     gcnt[p] = cnt;
                     int4 *e = reinterpret_cast<int4 *>(gedge + (size_t)p * kGraphEdges);
                     e[0] = make_int4(le[0], le[1], le[2], le[3]);
@@ -803,7 +819,7 @@ __global__ __launch_bounds__(kSegThreads) void k_graph_resolve(GraphArgs a, cons
     int nkept = 0;
     for (int i0 = 0; i0 < K && nkept < max_out; i0 += kSegThreads) {
         const int i = i0 + tid;
-        const bool kept = i < K && status[i] == kKept;
+        const bool kept = i < K && st_get(i) == kKept;
         int total;
         const int rank = tile_rank_rows(kept, s_bal, total);
         if (kept && nkept + rank < max_out) a.kept_slot[reg + nkept + rank] = a.sslot[reg + i];
