@@ -273,6 +273,19 @@ def test_v3_ties_in_the_sort_key_of_small_segments(pkg, dev):
     assert got.shape == want.shape and np.array_equal(got, want)
 
 
+def test_v3_ties_of_a_few_candidates_in_the_sort_key(pkg, dev):
+    """A handful of candidates of a class share their objectness (groups of 2 to 5, two groups with
+    adjacent values), next to an image with 35 such pairs and one with none: the order inside a
+    group is the anchor order."""
+    from tie_cases import few_ties_rows
+    util = pkg.util
+    rows = few_ties_rows()
+    want, surv, _ = oracle.n_write_results(rows, 0.5, 3, 0.4)
+    assert surv.max() == rows.shape[1] and want.shape[0] > 100
+    got = util.write_results(torch.from_numpy(rows).to(dev), 0.5, 3, 0.4).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
 def test_v3_empty_result_returns_zero(pkg, dev):
     util = pkg.util
     pred = torch.zeros((2, 100, 10), device=dev)

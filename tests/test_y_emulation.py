@@ -259,6 +259,28 @@ def test_emulated_write_results_with_equal_scores(pkg, emu):
     assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
 
 
+def test_emulated_write_results_with_a_few_equal_scores(pkg, emu):
+    """A handful of candidates of a class share their objectness (groups of 2 to 5), an image with
+    35 such pairs, an image with none: ordered by anchor index inside a group on both NMS kernels."""
+    from tie_cases import few_ties_rows
+    util = pkg.util
+    rows = few_ties_rows(N=400)
+    B, N, C = rows.shape[0], rows.shape[1], 3
+    want, surv, _ = oracle.n_write_results(rows, 0.5, C, 0.4)
+    assert want.shape[0] > 50
+    p = util._v3_params(B, C, 0.5, 0.4)
+    need = emu.yp_rows_workspace_bytes(B, N, C)
+    ws = aligned(need, fill=0xA5)
+    out = aligned(B * N * 32, 16).view(np.float32).reshape(B * N, 8)
+    n = np.zeros(1, np.int32)
+    rc = emu.yp_write_results(rows.ctypes.data, N, ctypes.byref(p), out.ctypes.data, B * N, n.ctypes.data, None,
+                              ws.ctypes.data, need, None)
+    assert rc == 0 and n[0] == len(want)
+    assert np.array_equal(out[:n[0]], want)
+    c = emul_counters(emu)
+    assert c["divergent"] == 0 and c["shuffle_from_inactive"] == 0, c
+
+
 def test_emulated_reference_mode(pkg, emu):
     """yp_detect_reference (detect_net.py:90-183 in one pass) against the oracle."""
     L, P = pkg._lib, pkg.params
